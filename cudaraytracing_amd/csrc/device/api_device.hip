@@ -1,0 +1,621 @@
+// Device half of the C ABI: context, scene upload (BVH build + re-layout) and
+// kernel launches.  Plays the part of Renderer::DoRendering
+// (renderer/renderer.cu:16-73) with the pass loop left to the caller.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../host/host.h"
+#include "kernels.hip"
+
+using namespace crt;
+
+struct crt_ctx {
+    int device = 0;
+    std::string error;
+    bool have_scene = false;
+    DevScene S{};
+    DevPartition P{};
+    std::vector<void*> allocs;                 // everything owned by the current scene
+    uint8_t* rgb8 = nullptr;
+    uint32_t* queue = nullptr;
+    DevStats* stats = nullptr;
+    std::map<int, uint32_t*> jumps;            // pass -> 160 x 5 jump matrix on the device
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int num_cus = 0;
+    size_t lds_bytes = 0;
+    int blocks_per_cu = 0, blocks_per_cu_counted = 0;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            (ctx)->error = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return CRT_E_HIP;                                                                           \
+        }                                                                                               \
+    } while (0)
+
+int fail(crt_ctx* ctx, int code, const std::string& msg) { ctx->error = msg; return code; }
+
+void free_scene(crt_ctx* ctx) {
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    ctx->allocs.clear();
+    for (auto& kv : ctx->jumps) (void)hipFree(kv.second);
+    ctx->jumps.clear();
+    ctx->rgb8 = nullptr;
+    ctx->have_scene = false;
+}
+
+template <typename T>
+int upload(crt_ctx* ctx, const std::vector<T>& host, const T** dev) {
+    void* p = nullptr;
+    const size_t bytes = host.size() * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(&p, bytes ? bytes : 16));
+    ctx->allocs.push_back(p);
+    if (bytes) HIP_TRY(ctx, hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice));
+    *dev = (const T*)p;
+    return CRT_OK;
+}
+
+// ---- XORWOW sequence jump: the 160x160 GF(2) matrix of "advance the xorshift part by
+// pass * 2^67 steps" (what curand_init does with its subsequence argument).
+struct BitMat { uint32_t row[160][5]; };
+
+void mat_apply(const BitMat& m, const uint32_t in[5], uint32_t out[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; w++)
+        for (int b = 0; b < 32; b++)
+            if (in[w] & (1u << b))
+                for (int k = 0; k < 5; k++) r[k] ^= m.row[w * 32 + b][k];
+    for (int k = 0; k < 5; k++) out[k] = r[k];
+}
+
+// c = "a then b"
+void mat_mul(const BitMat& a, const BitMat& b, BitMat& c) {
+    for (int r = 0; r < 160; r++) mat_apply(b, a.row[r], c.row[r]);
+}
+
+const BitMat& subsequence_step() {
+    static BitMat base;
+    static bool ready = false;
+    if (!ready) {
+        BitMat a, t;
+        for (int r = 0; r < 160; r++) {
+            uint32_t v[5] = {0, 0, 0, 0, 0};
+            v[r / 32] = 1u << (r % 32);
+            const uint32_t x = v[0] ^ (v[0] >> 2);
+            uint32_t o[5] = {v[1], v[2], v[3], v[4], (v[4] ^ (v[4] << 4)) ^ (x ^ (x << 1))};
+            memcpy(a.row[r], o, sizeof o);
+        }
+        for (int i = 0; i < 67; i++) { mat_mul(a, a, t); a = t; }
+        base = a;
+        ready = true;
+    }
+    return base;
+}
+
+void jump_for_pass(unsigned pass, BitMat& out) {
+    BitMat result, sq = subsequence_step(), t;
+    bool have = false;
+    for (unsigned p = pass; p; p >>= 1) {
+        if (p & 1u) {
+            if (!have) { result = sq; have = true; }
+            else { mat_mul(result, sq, t); result = t; }
+        }
+        if (p >> 1) { mat_mul(sq, sq, t); sq = t; }
+    }
+    out = result;
+}
+
+int get_jump(crt_ctx* ctx, int pass, const uint32_t** dev) {
+    *dev = nullptr;
+    if (pass == 0) return CRT_OK;
+    auto it = ctx->jumps.find(pass);
+    if (it == ctx->jumps.end()) {
+        BitMat m;
+        jump_for_pass((unsigned)pass, m);
+        uint32_t* p = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&p, sizeof m.row));
+        HIP_TRY(ctx, hipMemcpy(p, m.row, sizeof m.row, hipMemcpyHostToDevice));
+        it = ctx->jumps.emplace(pass, p).first;
+    }
+    *dev = it->second;
+    return CRT_OK;
+}
+
+int validate_desc(crt_ctx* ctx, const crt_scene_desc* d) {
+    if (!d) return fail(ctx, CRT_E_INVALID, "null scene");
+    if (d->camera.width == 0 || d->camera.height == 0) return fail(ctx, CRT_E_INVALID, "image size is zero");
+    if ((uint64_t)d->camera.width * d->camera.height > 0x7fffffffull / 3) return fail(ctx, CRT_E_INVALID, "image too large");
+    if (d->node_count == 0 || !d->nodes) return fail(ctx, CRT_E_INVALID, "scene has no nodes");
+    if (d->material_count == 0 || !d->materials) return fail(ctx, CRT_E_INVALID, "scene has no materials");
+    if (d->texture_count == 0 || !d->textures) return fail(ctx, CRT_E_INVALID, "scene has no textures");
+    if (d->env_texture < 0 || (uint32_t)d->env_texture >= d->texture_count) return fail(ctx, CRT_E_INVALID, "environment texture index out of range");
+    for (uint32_t i = 0; i < d->texture_count; i++) {
+        const crt_texture& t = d->textures[i];
+        if ((uint64_t)t.width * t.height > 0 && !t.rgb) return fail(ctx, CRT_E_INVALID, "texture without texels");
+    }
+    for (uint32_t i = 0; i < d->material_count; i++) {
+        const crt_material& m = d->materials[i];
+        for (int id : {m.diffuse, m.specular, m.refraction, m.emission})
+            if (id < 0 || (uint32_t)id >= d->texture_count) return fail(ctx, CRT_E_INVALID, "material texture index out of range");
+    }
+    for (uint32_t i = 0; i < d->light_count; i++)
+        if (d->lights[i].kind < CRT_LIGHT_AMBIENT || d->lights[i].kind > CRT_LIGHT_POINT) return fail(ctx, CRT_E_INVALID, "bad light kind");
+    for (uint32_t i = 0; i < d->mesh_count; i++) {
+        const crt_mesh& m = d->meshes[i];
+        if ((m.nv && !m.v) || (m.nf && !m.f)) return fail(ctx, CRT_E_INVALID, "mesh without vertex / face arrays");
+        if (m.nvn && (!m.vn || !m.fn)) return fail(ctx, CRT_E_INVALID, "mesh normals without index triples");
+        if (m.nvt && (!m.vt || !m.ft)) return fail(ctx, CRT_E_INVALID, "mesh texture vertices without index triples");
+        if (m.nf > 0x07ffffffu) return fail(ctx, CRT_E_LIMIT, "mesh has more than 2^27 faces");
+        for (uint32_t k = 0; k < 3 * m.nf; k++) {
+            if (m.f[k] >= m.nv) return fail(ctx, CRT_E_INVALID, "mesh vertex index out of range");
+            if (m.nvn && m.fn[k] >= m.nvn) return fail(ctx, CRT_E_INVALID, "mesh normal index out of range");
+            if (m.nvt && m.ft[k] >= m.nvt) return fail(ctx, CRT_E_INVALID, "mesh texture index out of range");
+        }
+    }
+    // child counts must describe a depth-first forest that ends exactly at node_count
+    for (uint32_t i = 0; i < d->node_count; i++) {
+        const crt_node& n = d->nodes[i];
+        if (n.object_kind < CRT_OBJ_NONE || n.object_kind > CRT_OBJ_MESH) return fail(ctx, CRT_E_INVALID, "bad object kind");
+        if (n.object_kind == CRT_OBJ_MESH && (n.mesh_id < 0 || (uint32_t)n.mesh_id >= d->mesh_count)) return fail(ctx, CRT_E_INVALID, "node mesh index out of range");
+        if (n.material_id < 0 || (uint32_t)n.material_id >= d->material_count) return fail(ctx, CRT_E_INVALID, "node material index out of range");
+    }
+    return CRT_OK;
+}
+
+// index of the first node after node i's subtree, from the depth-first child counts
+void subtree_ends(const crt_scene_desc* d, std::vector<uint32_t>& after) {
+    const uint32_t n = d->node_count;
+    after.assign(n, n);
+    // iterative: process nodes in reverse so children are known
+    std::vector<uint32_t> size(n, 1);
+    for (int i = (int)n - 1; i >= 0; i--) {
+        uint32_t j = (uint32_t)i + 1, total = 1;
+        for (uint32_t c = 0; c < d->nodes[i].child_count && j < n; c++) { total += size[j]; j += size[j]; }
+        size[i] = total;
+        after[i] = (uint32_t)i + total > n ? n : (uint32_t)i + total;
+    }
+}
+
+void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_rows) {
+    DevPartition& P = ctx->P;
+    P.part = part; P.parts = parts; P.strip_rows = strip_rows;
+    P.tiles_x = (ctx->S.width + 7) / 8;
+    P.items_per_strip = P.tiles_x * (strip_rows / 8) * 64;
+    const uint32_t strips = (ctx->S.height + strip_rows - 1) / strip_rows;
+    const uint32_t owned = strips > part ? (strips - part + parts - 1) / parts : 0;
+    P.total_items = owned * P.items_per_strip;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crt_create(int device, crt_ctx** out) {
+    if (!out) return CRT_E_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { crt::set_host_error("no HIP device available"); return CRT_E_HIP; }
+    if (device < 0 || device >= count) { crt::set_host_error("device index out of range"); return CRT_E_INVALID; }
+    crt_ctx* ctx = new crt_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete ctx; crt::set_host_error("cannot select HIP device"); return CRT_E_HIP;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void**)&ctx->queue, 256) != hipSuccess || hipMalloc((void**)&ctx->stats, sizeof(DevStats)) != hipSuccess ||
+        hipMemset(ctx->stats, 0, sizeof(DevStats)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx; crt::set_host_error("cannot allocate context buffers"); return CRT_E_HIP;
+    }
+    *out = ctx;
+    return CRT_OK;
+}
+
+void crt_destroy(crt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_scene(ctx);
+    if (ctx->queue) (void)hipFree(ctx->queue);
+    if (ctx->stats) (void)hipFree(ctx->stats);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char* crt_last_error(const crt_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
+    if (!ctx) return CRT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = validate_desc(ctx, d);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    free_scene(ctx);
+
+    const uint32_t N = d->node_count;
+    std::vector<uint32_t> after;
+    subtree_ends(d, after);
+
+    // ---- BVH per mesh, then the global record arrays
+    std::vector<HostBvh> bvhs(d->mesh_count);
+    uint32_t max_depth = 1;
+    for (uint32_t m = 0; m < d->mesh_count; m++) {
+        const crt_mesh& M = d->meshes[m];
+        std::string err;
+        if (!bvh_build(M.v, M.nv, M.f, M.nf, M.box_min, M.box_max, bvhs[m], err))
+            return fail(ctx, err.find("depth") != std::string::npos ? CRT_E_LIMIT : CRT_E_INVALID, "mesh " + std::to_string(m) + ": " + err);
+        if (bvhs[m].depth > max_depth) max_depth = bvhs[m].depth;
+    }
+
+    std::vector<BoxPair> pairs(N);
+    std::vector<TriRec> tris;
+    std::vector<uint32_t> mesh_root(d->mesh_count, 0);
+    auto node_half = [&](uint32_t i, float* bmin, float* bmax, uint32_t& ref) {
+        if (i < N) {
+            memcpy(bmin, d->nodes[i].box_min, 12); memcpy(bmax, d->nodes[i].box_max, 12);
+            ref = (uint32_t)d->nodes[i].object_kind | (after[i] << 2);
+        } else {
+            for (int k = 0; k < 3; k++) { bmin[k] = CRT_BIGFLOAT; bmax[k] = -CRT_BIGFLOAT; }
+            ref = CRT_OBJ_NONE | (N << 2);
+        }
+    };
+    for (uint32_t i = 0; i < N; i++) {
+        BoxPair& p = pairs[i];
+        node_half(i, p.a_min, p.a_max, p.ref_a);
+        node_half(i + 1, p.b_min, p.b_max, p.ref_b);
+        p.aux_a = p.aux_b = 0;
+    }
+    for (uint32_t m = 0; m < d->mesh_count; m++) {
+        const crt_mesh& M = d->meshes[m];
+        const HostBvh& B = bvhs[m];
+        const uint32_t tri_base = (uint32_t)tris.size();
+        if ((uint64_t)tri_base + M.nf > 0x07ffffffull) return fail(ctx, CRT_E_LIMIT, "more than 2^27 triangles in the scene");
+        for (uint32_t s = 0; s < M.nf; s++) {
+            const uint32_t face = B.elements[s];
+            TriRec t{};
+            memcpy(t.p0, M.v + 3 * M.f[3 * face], 12);
+            memcpy(t.p1, M.v + 3 * M.f[3 * face + 1], 12);
+            memcpy(t.p2, M.v + 3 * M.f[3 * face + 2], 12);
+            t.face = face;
+            tris.push_back(t);
+        }
+        // interior nodes get consecutive records in node order
+        const uint32_t nn = B.node_count();
+        std::vector<uint32_t> rec_of(nn, 0);
+        uint32_t next_rec = (uint32_t)pairs.size();
+        for (uint32_t i = 0; i < nn; i++) if (!B.leaf[i]) rec_of[i] = next_rec++;
+        auto ref_of = [&](uint32_t i) -> uint32_t {
+            if (B.leaf[i]) return make_leaf_ref(tri_base + B.elem_start[i], B.elem_count[i]);
+            return rec_of[i];
+        };
+        for (uint32_t i = 0; i < nn; i++) {
+            if (B.leaf[i]) { if (B.elem_count[i] > 15) return fail(ctx, CRT_E_LIMIT, "BVH leaf with more than 15 elements"); continue; }
+            BoxPair p{};
+            const uint32_t l = B.left[i], r = B.right[i];
+            memcpy(p.a_min, &B.box[6 * l], 12); memcpy(p.a_max, &B.box[6 * l + 3], 12);
+            memcpy(p.b_min, &B.box[6 * r], 12); memcpy(p.b_max, &B.box[6 * r + 3], 12);
+            p.ref_a = ref_of(l); p.ref_b = ref_of(r);
+            pairs.push_back(p);
+        }
+        mesh_root[m] = nn ? ref_of(0) : make_leaf_ref(tri_base, 0);
+    }
+    if (pairs.size() >= 0x80000000ull) return fail(ctx, CRT_E_LIMIT, "too many BVH nodes");
+
+    std::vector<NodeXf> xf(N);
+    for (uint32_t i = 0; i < N; i++) {
+        const crt_node& n = d->nodes[i];
+        memcpy(xf[i].itm, n.itm, 48); memcpy(xf[i].tm, n.tm, 48);
+        xf[i].mesh_id = n.object_kind == CRT_OBJ_MESH ? n.mesh_id : -1;
+        xf[i].root_ref = n.object_kind == CRT_OBJ_MESH ? mesh_root[n.mesh_id] : 0;
+        xf[i].material_id = n.material_id;
+        xf[i].pad = 0;
+    }
+
+    std::vector<DevMesh> meshes(d->mesh_count ? d->mesh_count : 1);
+    for (uint32_t m = 0; m < d->mesh_count; m++) {
+        const crt_mesh& M = d->meshes[m];
+        DevMesh dm{};
+        dm.has_normals = M.nvn > 0; dm.has_tex = M.nvt > 0;
+        if (dm.has_normals) {
+            std::vector<float> vn(M.vn, M.vn + 3ull * M.nvn);
+            std::vector<uint32_t> fn(M.fn, M.fn + 3ull * M.nf);
+            if ((rc = upload(ctx, vn, &dm.vn)) || (rc = upload(ctx, fn, &dm.fn))) return rc;
+        }
+        if (dm.has_tex) {
+            std::vector<float> vt(M.vt, M.vt + 3ull * M.nvt);
+            std::vector<uint32_t> ft(M.ft, M.ft + 3ull * M.nf);
+            if ((rc = upload(ctx, vt, &dm.vt)) || (rc = upload(ctx, ft, &dm.ft))) return rc;
+        }
+        meshes[m] = dm;
+    }
+
+    std::vector<DevTexture> textures(d->texture_count);
+    std::vector<uint8_t> texels;
+    for (uint32_t i = 0; i < d->texture_count; i++) {
+        const crt_texture& t = d->textures[i];
+        textures[i].width = t.width; textures[i].height = t.height; textures[i].offset = (uint32_t)texels.size(); textures[i].pad = 0;
+        const size_t bytes = (size_t)t.width * t.height * 3;
+        if (texels.size() + bytes > 0xffffffffull) return fail(ctx, CRT_E_LIMIT, "more than 4 GiB of texels");
+        if (bytes) texels.insert(texels.end(), t.rgb, t.rgb + bytes);
+    }
+    texels.resize(texels.size() + 16, 0);
+
+    std::vector<DevMaterial> materials(d->material_count);
+    for (uint32_t i = 0; i < d->material_count; i++) {
+        const crt_material& m = d->materials[i];
+        DevMaterial dm{};
+        dm.diffuse = m.diffuse; dm.specular = m.specular; dm.refraction = m.refraction; dm.emission = m.emission;
+        dm.glossiness = m.glossiness; dm.ior = m.ior;
+        memcpy(dm.absorption, m.absorption, 12);
+        materials[i] = dm;
+    }
+
+    std::vector<DevLight> lights(d->light_count ? d->light_count : 1);
+    for (uint32_t i = 0; i < d->light_count; i++) {
+        const crt_light& l = d->lights[i];
+        DevLight dl{};
+        dl.kind = l.kind; dl.size = l.size;
+        memcpy(dl.intensity, l.intensity, 12); memcpy(dl.pos, l.vec, 12);
+        // PointLight::Radiance (scene/lights.cuh:62): the factor is a double expression narrowed to float
+        const float k = l.kind == CRT_LIGHT_POINT ? (float)(1.0f / (3.14159265358979323846 * l.size * l.size)) : 1.0f;
+        for (int c = 0; c < 3; c++) dl.radiance[c] = l.kind == CRT_LIGHT_POINT ? l.intensity[c] * k : l.intensity[c];
+        lights[i] = dl;
+    }
+
+    DevScene& S = ctx->S;
+    memset(&S, 0, sizeof S);
+    const crt_camera& cam = d->camera;
+    S.width = cam.width; S.height = cam.height;
+    memcpy(S.cam_pos, cam.position, 12); S.dof = cam.dof; S.pixel_size = cam.pixel_size;
+    memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
+    S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
+    S.stack_entries = max_depth + 2;
+    if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
+        (rc = upload(ctx, meshes, &S.meshes)) || (rc = upload(ctx, materials, &S.materials)) ||
+        (rc = upload(ctx, textures, &S.textures)) || (rc = upload(ctx, texels, &S.texels)) || (rc = upload(ctx, lights, &S.lights)))
+        return rc;
+
+    const size_t px = (size_t)cam.width * cam.height;
+    float* acc[3];
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(ctx, hipMalloc((void**)&acc[k], px * 12));
+        ctx->allocs.push_back(acc[k]);
+        HIP_TRY(ctx, hipMemset(acc[k], 0, px * 12));
+    }
+    S.results = acc[0]; S.normals = acc[1]; S.albedos = acc[2];
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->rgb8, px * 3));
+    ctx->allocs.push_back(ctx->rgb8);
+    HIP_TRY(ctx, hipMemset(ctx->rgb8, 0, px * 3));
+    HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
+
+    // two LDS arrays (node reference, entry distance) of stack_entries x 256 words
+    ctx->lds_bytes = (size_t)S.stack_entries * CRT_BLOCK * 4 * 2;
+    if (ctx->lds_bytes > 160 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)primary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, render_kernel<false>, CRT_BLOCK, ctx->lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, render_kernel<true>, CRT_BLOCK, ctx->lds_bytes));
+    if (ctx->blocks_per_cu < 1) ctx->blocks_per_cu = 1;
+    if (ctx->blocks_per_cu_counted < 1) ctx->blocks_per_cu_counted = 1;
+
+    ctx->have_scene = true;
+    ctx->timed = false;
+    set_partition(ctx, 0, 1, 16);
+    return CRT_OK;
+}
+
+int crt_set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_rows) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    if (parts == 0 || part >= parts || strip_rows == 0 || strip_rows % 8 != 0) return fail(ctx, CRT_E_INVALID, "bad partition (strip_rows must be a positive multiple of 8)");
+    const uint64_t strips = (ctx->S.height + strip_rows - 1) / strip_rows;
+    const uint64_t items = strips * ((ctx->S.width + 7) / 8) * (strip_rows / 8) * 64;
+    if (items > 0x7fffffffull) return fail(ctx, CRT_E_LIMIT, "image too large for the pixel queue");
+    set_partition(ctx, part, parts, strip_rows);
+    return CRT_OK;
+}
+
+int crt_clear(crt_ctx* ctx) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)ctx->S.width * ctx->S.height;
+    HIP_TRY(ctx, hipMemset(ctx->S.results, 0, px * 12));
+    HIP_TRY(ctx, hipMemset(ctx->S.normals, 0, px * 12));
+    HIP_TRY(ctx, hipMemset(ctx->S.albedos, 0, px * 12));
+    HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return CRT_OK;
+}
+
+static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t stream, bool async, bool counted) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    if (pass_id < 0 || samples <= 0) return fail(ctx, CRT_E_INVALID, "pass_id must be >= 0 and samples > 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t* jump = nullptr;
+    int rc = get_jump(ctx, pass_id, &jump);
+    if (rc) return rc;
+    if (ctx->P.total_items == 0) return CRT_OK;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->queue, 0, 4, stream));
+    const int per_cu = counted ? ctx->blocks_per_cu_counted : ctx->blocks_per_cu;
+    uint32_t grid = (uint32_t)(ctx->num_cus * per_cu);
+    const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
+    if (grid > need) grid = need;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (counted)
+        hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    if (!async) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return CRT_OK;
+}
+
+int crt_render_pass(crt_ctx* ctx, int pass_id, int samples, void* stream, int async) {
+    return render_impl(ctx, pass_id, samples, (hipStream_t)stream, async != 0, false);
+}
+
+int crt_render_pass_counted(crt_ctx* ctx, int pass_id, int samples) {
+    return render_impl(ctx, pass_id, samples, nullptr, false, true);
+}
+
+int crt_last_kernel_ms(crt_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return CRT_E_INVALID;
+    if (!ctx->timed) return fail(ctx, CRT_E_INVALID, "no render pass has been launched");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return CRT_OK;
+}
+
+int crt_convert(crt_ctx* ctx, float pass_mul, int srgb, void* rgb_out_device, void* stream, int async) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->S.width * ctx->S.height;
+    uint8_t* out = rgb_out_device ? (uint8_t*)rgb_out_device : ctx->rgb8;
+    hipLaunchKernelGGL(convert_kernel, dim3((n + CRT_BLOCK - 1) / CRT_BLOCK), dim3(CRT_BLOCK), 0, (hipStream_t)stream,
+                       ctx->S.results, out, n, srgb, pass_mul);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!async) HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return CRT_OK;
+}
+
+int crt_read_image(crt_ctx* ctx, uint8_t* rgb_host) {
+    if (!ctx || !rgb_host) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(rgb_host, ctx->rgb8, (size_t)ctx->S.width * ctx->S.height * 3, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_read_accumulators(crt_ctx* ctx, float* results, float* normals, float* albedos) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->S.width * ctx->S.height * 12;
+    if (results) HIP_TRY(ctx, hipMemcpy(results, ctx->S.results, bytes, hipMemcpyDeviceToHost));
+    if (normals) HIP_TRY(ctx, hipMemcpy(normals, ctx->S.normals, bytes, hipMemcpyDeviceToHost));
+    if (albedos) HIP_TRY(ctx, hipMemcpy(albedos, ctx->S.albedos, bytes, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_device_buffers(crt_ctx* ctx, void** results, void** normals, void** albedos, void** rgb8) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    if (results) *results = ctx->S.results;
+    if (normals) *normals = ctx->S.normals;
+    if (albedos) *albedos = ctx->S.albedos;
+    if (rgb8) *rgb8 = ctx->rgb8;
+    return CRT_OK;
+}
+
+int crt_primary_hits(crt_ctx* ctx, int pass_id, int32_t* node, int32_t* face, float* t) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    if (pass_id < 0) return fail(ctx, CRT_E_INVALID, "pass_id must be >= 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t* jump = nullptr;
+    int rc = get_jump(ctx, pass_id, &jump);
+    if (rc) return rc;
+    const size_t px = (size_t)ctx->S.width * ctx->S.height;
+    int32_t *d_node = nullptr, *d_face = nullptr;
+    float* d_t = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_node, px * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d_face, px * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d_t, px * 4));
+    // pixels this context does not own read as "not traced"
+    HIP_TRY(ctx, hipMemset(d_node, 0xff, px * 4));
+    HIP_TRY(ctx, hipMemset(d_face, 0xff, px * 4));
+    HIP_TRY(ctx, hipMemset(d_t, 0, px * 4));
+    if (ctx->P.total_items) {
+        hipLaunchKernelGGL(primary_kernel, dim3((ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK), dim3(CRT_BLOCK), ctx->lds_bytes, nullptr,
+                           ctx->S, ctx->P, jump, d_node, d_face, d_t);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (node) HIP_TRY(ctx, hipMemcpy(node, d_node, px * 4, hipMemcpyDeviceToHost));
+    if (face) HIP_TRY(ctx, hipMemcpy(face, d_face, px * 4, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(ctx, hipMemcpy(t, d_t, px * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_node); (void)hipFree(d_face); (void)hipFree(d_t);
+    return CRT_OK;
+}
+
+int crt_get_stats(crt_ctx* ctx, crt_stats* out) {
+    if (!ctx || !out) return CRT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevStats s;
+    HIP_TRY(ctx, hipMemcpy(&s, ctx->stats, sizeof s, hipMemcpyDeviceToHost));
+    out->closest_rays = s.closest_rays; out->shadow_rays = s.shadow_rays; out->paths = s.paths;
+    out->node_box_tests = s.node_box_tests; out->node_enters = s.node_enters; out->bvh_interior = s.bvh_interior;
+    out->bvh_leaves = s.bvh_leaves; out->tri_tests = s.tri_tests; out->tri_hits = s.tri_hits;
+    out->sphere_tests = s.sphere_tests; out->plane_tests = s.plane_tests; out->texel_quads = s.texel_quads;
+    return CRT_OK;
+}
+
+int crt_rng_selftest(crt_ctx* ctx, const uint32_t* seeds, const uint32_t* subsequences, uint32_t n, uint32_t draws, uint32_t* out) {
+    if (!ctx || !seeds || !subsequences || !out || n == 0) return CRT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // one jump matrix per distinct non-zero subsequence
+    std::map<uint32_t, uint32_t> slot;
+    std::vector<uint32_t> mats, index(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (subsequences[i] == 0) { index[i] = 0xffffffffu; continue; }
+        auto it = slot.find(subsequences[i]);
+        if (it == slot.end()) {
+            BitMat m;
+            jump_for_pass(subsequences[i], m);
+            it = slot.emplace(subsequences[i], (uint32_t)(mats.size() / 800)).first;
+            mats.insert(mats.end(), &m.row[0][0], &m.row[0][0] + 800);
+        }
+        index[i] = it->second;
+    }
+    uint32_t *d_seeds = nullptr, *d_index = nullptr, *d_mats = nullptr, *d_out = nullptr;
+    const size_t out_words = (size_t)n * (6 + draws);
+    HIP_TRY(ctx, hipMalloc((void**)&d_seeds, n * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d_index, n * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d_mats, mats.size() * 4 + 16));
+    HIP_TRY(ctx, hipMalloc((void**)&d_out, out_words * 4));
+    HIP_TRY(ctx, hipMemcpy(d_seeds, seeds, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_index, index.data(), n * 4, hipMemcpyHostToDevice));
+    if (!mats.empty()) HIP_TRY(ctx, hipMemcpy(d_mats, mats.data(), mats.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rng_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, d_seeds, d_index, d_mats, n, draws, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(out, d_out, out_words * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_seeds); (void)hipFree(d_index); (void)hipFree(d_mats); (void)hipFree(d_out);
+    return CRT_OK;
+}
+
+int crt_math_selftest(crt_ctx* ctx, int fn, const float* x, const float* y, uint32_t n, float* out) {
+    if (!ctx || !x || !out || n == 0 || fn < 0 || fn > 7) return CRT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_x = nullptr, *d_y = nullptr, *d_o = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_x, n * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d_y, n * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d_o, n * 4));
+    HIP_TRY(ctx, hipMemcpy(d_x, x, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_y, y ? y : x, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(math_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, fn, d_x, d_y, n, d_o);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(out, d_o, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_o);
+    return CRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// Device-side scene layout (what crt_upload_scene builds in HBM).
+//
+// Everything a ray touches while it walks the scene is one of two record
+// arrays, so a lane's whole traversal state is a 32-bit record index:
+//
+//  * box-pair records (64 B, one cache line, fetched as 4 x dwordx4 per lane):
+//    two boxes and two 32-bit references.  Records [0, node_count) describe the
+//    scene's node list: record i holds the world boxes of node i and node i+1,
+//    so the linear node scan of the reference (renderer/trace.cu:51-68,
+//    166-193) advances two nodes per fetch.  The records after that are the
+//    interior nodes of every mesh BVH: the boxes of the left and the right
+//    child, which the reference keeps in two different 72-byte nodes
+//    (renderer/bvh.cuh:13-35) and therefore reads through two more lines.
+//  * triangle records (48 B, 3 x dwordx4): the three vertices of one BVH
+//    element, gathered in leaf order at upload, so a leaf's triangles are
+//    consecutive and the element -> face -> vertex indirection of
+//    MeshObject::IntersectTriangle (scene/objects.cu:273-276) is gone from the
+//    loop.  The w lane of the first vertex carries the original face index.
+#pragma once
+#include <stdint.h>
+
+#include "../crt_vec.h"
+
+namespace crt {
+
+struct alignas(16) BoxPair {
+    float a_min[3], a_max[3];
+    float b_min[3], b_max[3];
+    uint32_t ref_a, ref_b;
+    uint32_t aux_a, aux_b;
+};
+static_assert(sizeof(BoxPair) == 64, "BoxPair must be one 64-byte line");
+
+// BVH child reference.  Leaf: bit 31 set, bits 30..27 = triangle count (0..8),
+// bits 26..0 = first triangle record.  Interior: absolute box-pair record index.
+constexpr uint32_t kRefLeaf = 0x80000000u;
+constexpr uint32_t kRefNone = 0xffffffffu;     // only as "stack empty" marker
+CRT_HD uint32_t make_leaf_ref(uint32_t start, uint32_t count) { return kRefLeaf | (count << 27) | start; }
+CRT_HD bool ref_is_leaf(uint32_t r) { return (r & kRefLeaf) != 0; }
+CRT_HD uint32_t leaf_start(uint32_t r) { return r & 0x07ffffffu; }
+CRT_HD uint32_t leaf_count(uint32_t r) { return (r >> 27) & 0xfu; }
+
+// Scene-node half of a box pair: ref = object kind (2 bits) | (index of the
+// first node after this node's subtree << 2); aux unused.
+CRT_HD uint32_t node_ref_kind(uint32_t r) { return r & 3u; }
+CRT_HD uint32_t node_ref_after(uint32_t r) { return r >> 2; }
+
+struct alignas(16) TriRec {
+    float p0[3]; uint32_t face;
+    float p1[3]; uint32_t pad1;
+    float p2[3]; uint32_t pad2;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec is three 16-byte loads");
+
+// Per scene node, read only when a ray enters the node.
+struct alignas(16) NodeXf {
+    float itm[12];      // world -> local
+    float tm[12];       // local -> world
+    uint32_t root_ref;  // mesh: BVH root reference
+    int32_t mesh_id;
+    int32_t material_id;
+    uint32_t pad;
+};
+static_assert(sizeof(NodeXf) == 112, "NodeXf layout");
+
+// Per mesh, read only when a closest hit on it is finalised.
+struct DevMesh {
+    const float* vn;        // normals, xyz
+    const uint32_t* fn;     // normal index triples per face
+    const float* vt;
+    const uint32_t* ft;
+    uint32_t has_normals, has_tex;
+};
+
+struct DevTexture {
+    uint32_t width, height;
+    uint32_t offset;        // byte offset of texel (0,0) in the texel pool
+    uint32_t pad;
+};
+
+struct DevMaterial {
+    int32_t diffuse, specular, refraction, emission;
+    float glossiness, ior;
+    float absorption[3];
+    float pad;
+};
+
+struct DevLight {
+    int32_t kind;
+    float intensity[3];
+    float pos[3];
+    float size;
+    float radiance[3];      // intensity * float(1 / (pi * size^2)) for point lights
+    float pad;
+};
+
+struct DevScene {
+    // camera / render info
+    uint32_t width, height;
+    float cam_pos[3]; float dof;
+    float pixel_size;
+    float cX[3], cY[3];
+    float top_left[3];
+    // scene
+    uint32_t node_count, light_count;
+    int32_t env_texture;
+    uint32_t stack_entries;          // LDS stack slots per lane
+    const BoxPair* pairs;
+    const TriRec* tris;
+    const NodeXf* xf;
+    const DevMesh* meshes;
+    const DevMaterial* materials;
+    const DevTexture* textures;
+    const uint8_t* texels;
+    const DevLight* lights;
+    // accumulators (W*H float3 each)
+    float* results;
+    float* normals;
+    float* albedos;
+};
+
+// Work partition: the image is cut into strips of strip_rows rows; this context
+// owns strips part, part + parts, ...  Inside a strip pixels are queued in 8x8
+// tiles so that the 64 lanes of a wave start on one tile.
+struct DevPartition {
+    uint32_t part, parts, strip_rows;
+    uint32_t tiles_x;            // ceil(width / 8)
+    uint32_t items_per_strip;    // tiles_x * (strip_rows / 8) * 64
+    uint32_t total_items;        // owned strips * items_per_strip
+};
+
+struct DevStats {
+    unsigned long long closest_rays, shadow_rays, paths;
+    unsigned long long node_box_tests, node_enters, bvh_interior, bvh_leaves;
+    unsigned long long tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
+};
+
+}  // namespace crt
