@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms/frame of the per-pixel trace path.
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on):
+scenes/final frame0042 at 1920x1080, 64 samples per pixel in one pass, image strips
+split over the N GPUs of one node, framebuffer gathered to rank 0 over RCCL.
+
+One "step" is one whole frame: clear accumulators, trace kernel, ConvertColors,
+gather of the owned rows to rank 0 and the device-to-host copy of the 8-bit image.
+The scene is resident in HBM before the timed region.  A ray is one closest-hit query
+or one shadow query toward a point light.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import cudaraytracing_amd as crt
+from cudaraytracing_amd.distributed import gather_rows
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X fp32 vector peak (FMA counted as 2)
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_work(c, pixels):
+    """Bytes and flops one launch needs by the counting rule of the design notes: 24 B per scene-node
+    box, 112 B per entered node (two transforms + tags), 56 B per expanded BVH interior node (two child
+    boxes + two references), 8 B per leaf, 36 B per triangle tested, 72 B per accepted triangle
+    (normals + texture vertices), 12 B per bilinear texture evaluation, 36 B of accumulators per pixel;
+    25 flops per slab test, 66 per node enter/leave, 55 per triangle, 40 per sphere, 15 per plane."""
+    nbytes = (24 * c["node_box_tests"] + 112 * c["node_enters"] + 56 * c["bvh_interior"] + 8 * c["bvh_leaves"] +
+              36 * c["tri_tests"] + 72 * c["tri_hits"] + 12 * c["texel_quads"] + 36 * pixels)
+    flops = (25 * (c["node_box_tests"] + 2 * c["bvh_interior"]) + 66 * c["node_enters"] + 55 * c["tri_tests"] +
+             40 * c["sphere_tests"] + 15 * c["plane_tests"])
+    return nbytes, flops
+
+
+def cpu_baseline(scene_file, width, height, spp, threads):
+    """Times the CPU oracle (glibc flavour, multithreaded) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    o = orc.OracleScene(scene_file, "glibc")
+    o.set_resolution(width, height)
+    t0 = time.perf_counter()
+    _, cnt = o.render(0, spp, threads=threads, count=True)
+    dt = time.perf_counter() - t0
+    rays = cnt["closest_rays"] + cnt["shadow_rays"]
+    return {"value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{os.path.basename(scene_file)} {width}x{height}, {spp} spp of the 64, all rows, {dt:.1f} s of wall time",
+            "ms_per_frame_extrapolated": dt * 1e3 * 64 / spp}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="final_frame0042")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--cpu-spp", type=int, default=2, help="samples per pixel of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline-counters", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    scene_file = os.path.join(ROOT, "tests", "golden", "scenes", args.scene + ".crtscene")
+    scene = crt.Scene.load_file(scene_file)
+    scene.set_resolution(args.width, args.height)
+    t0 = time.perf_counter()
+    ctx = crt.Context(local_rank)
+    ctx.upload(scene)                      # BVH build + re-layout + H2D, outside the timed region
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    ctx.set_partition(rank, world, 16)
+    H, W = args.height, args.width
+    rgb_dev = torch.zeros((H, W, 3), dtype=torch.uint8, device=device)
+    rgb_host = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
+    srgb = scene.srgb
+
+    def frame():
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.clear(stream=stream, wait=False)
+        ctx.render_pass(0, args.spp, stream=stream, wait=False)
+        ctx.convert(1.0, srgb, out_device_ptr=rgb_dev.data_ptr(), stream=stream, wait=False)
+        full = gather_rows(rgb_dev, rank, world, 16)
+        if rank == 0:
+            rgb_host.copy_(full, non_blocking=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    fence()
+    ctx.kernel_times()                      # drop warm-up launches
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.kernel_times()
+
+    st = ctx.stats()                        # counters of the last frame (cleared at each frame start)
+    rays = torch.tensor([st["closest_rays"] + st["shadow_rays"], st["closest_rays"], st["shadow_rays"]], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    rays_per_frame = float(rays[0].item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    roofline = None
+    if rank == 0 and not args.no_roofline_counters:
+        # traversal counters of this rank's share of the frame, from the counting build of the kernel (untimed)
+        ctx.clear()
+        ctx.render_pass_counted(0, args.spp)
+        c = ctx.stats()
+        ctx.kernel_times()
+        own_pixels = sum(1 for y in range(H) if (y // 16) % world == rank) * W
+        nbytes, flops = algorithmic_work(c, own_pixels)
+        k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+        roofline = {"bound": "valu", "kernel": "render_kernel", "achieved": flops / (k_ms * 1e-3) * 1e-12, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": flops / (k_ms * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                    "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(kernel_ms)),
+                    "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+                    "hbm": {"bound": "hbm", "achieved": nbytes / (k_ms * 1e-3) * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": nbytes / (k_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS},
+                    "note": "no MFMA on this path (not a dense contraction); scene working set is cache resident, so the binding "
+                            "roofline is fp32 vector issue; peak counts an FMA as 2 flops while the kernel is built without contraction"}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_spp > 0:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        cpu = cpu_baseline(scene_file, W, H, args.cpu_spp, threads)
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (scenes/final, 1080p, 64 spp)", "value": rays_per_frame / (ms_per_step * 1e-3) * 1e-6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "reference scene file (baked), fixed seeds",
+            "config": {"workload": f"scenes/final/frame0042.xml at {W}x{H}, {args.spp} spp in 1 pass, path-traced GI (BASELINE configs[3])",
+                       "scene": args.scene, "width": W, "height": H, "spp": args.spp, "passes": 1,
+                       "parallelism": f"16-row image strips round-robin over {world} GPU(s), scene replicated, RGB8 rows gathered to rank 0"},
+            "rays_per_frame": rays_per_frame, "closest_rays": float(rays[1].item()), "shadow_rays": float(rays[2].item()),
+            "frame_includes": "accumulator clear, trace kernel, ConvertColors, row gather, D2H of the 8-bit image",
+            "scene_upload_ms": upload_ms,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,6 +99,7 @@ _PROTOS = {
     "crt_upload_scene": (C.c_int, [_VP, C.POINTER(SceneDesc)]),
     "crt_set_partition": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32]),
     "crt_clear": (C.c_int, [_VP]),
+    "crt_clear_async": (C.c_int, [_VP, _VP]),
     "crt_render_pass": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int]),
     "crt_convert": (C.c_int, [_VP, C.c_float, C.c_int, _VP, _VP, C.c_int]),
     "crt_read_image": (C.c_int, [_VP, _VP]),
@@ -110,6 +111,7 @@ _PROTOS = {
     "crt_rng_selftest": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "crt_math_selftest": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_uint32, _VP]),
     "crt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "crt_kernel_times": (C.c_int, [_VP, _VP, C.c_uint32, C.POINTER(C.c_uint32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -26,8 +26,10 @@ struct crt_ctx {
     uint32_t* queue = nullptr;
     DevStats* stats = nullptr;
     std::map<int, uint32_t*> jumps;            // pass -> 160 x 5 jump matrix on the device
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    static constexpr int kRing = 256;
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};   // event pair per launch, ring buffer
+    uint64_t launches = 0;                          // launches recorded so far
+    uint64_t reported = 0;                          // launches already handed out by crt_kernel_times
     int num_cus = 0;
     size_t lds_bytes = 0;
     int blocks_per_cu = 0, blocks_per_cu_counted = 0;
@@ -214,10 +216,13 @@ int crt_create(int device, crt_ctx** out) {
     }
     ctx->num_cus = prop.multiProcessorCount;
     if (hipMalloc((void**)&ctx->queue, 256) != hipSuccess || hipMalloc((void**)&ctx->stats, sizeof(DevStats)) != hipSuccess ||
-        hipMemset(ctx->stats, 0, sizeof(DevStats)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipMemset(ctx->stats, 0, sizeof(DevStats)) != hipSuccess) {
         delete ctx; crt::set_host_error("cannot allocate context buffers"); return CRT_E_HIP;
     }
+    for (int i = 0; i < crt_ctx::kRing; i++)
+        if (hipEventCreate(&ctx->ev0[i]) != hipSuccess || hipEventCreate(&ctx->ev1[i]) != hipSuccess) {
+            delete ctx; crt::set_host_error("cannot create timing events"); return CRT_E_HIP;
+        }
     *out = ctx;
     return CRT_OK;
 }
@@ -229,8 +234,10 @@ void crt_destroy(crt_ctx* ctx) {
     free_scene(ctx);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->stats) (void)hipFree(ctx->stats);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < crt_ctx::kRing; i++) {
+        if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
+        if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
+    }
     delete ctx;
 }
 
@@ -412,7 +419,6 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     if (ctx->blocks_per_cu_counted < 1) ctx->blocks_per_cu_counted = 1;
 
     ctx->have_scene = true;
-    ctx->timed = false;
     set_partition(ctx, 0, 1, 16);
     return CRT_OK;
 }
@@ -428,15 +434,22 @@ int crt_set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t stri
     return CRT_OK;
 }
 
-int crt_clear(crt_ctx* ctx) {
+int crt_clear_async(crt_ctx* ctx, void* stream) {
     if (!ctx) return CRT_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)ctx->S.width * ctx->S.height;
-    HIP_TRY(ctx, hipMemset(ctx->S.results, 0, px * 12));
-    HIP_TRY(ctx, hipMemset(ctx->S.normals, 0, px * 12));
-    HIP_TRY(ctx, hipMemset(ctx->S.albedos, 0, px * 12));
-    HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->S.results, 0, px * 12, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->S.normals, 0, px * 12, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->S.albedos, 0, px * 12, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(DevStats), st));
+    return CRT_OK;
+}
+
+int crt_clear(crt_ctx* ctx) {
+    const int rc = crt_clear_async(ctx, nullptr);
+    if (rc) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     return CRT_OK;
 }
@@ -455,14 +468,15 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     uint32_t grid = (uint32_t)(ctx->num_cus * per_cu);
     const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
     if (grid > need) grid = need;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    const int slot = (int)(ctx->launches % crt_ctx::kRing);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], stream));
     if (counted)
         hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats);
     else
         hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-    ctx->timed = true;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], stream));
+    ctx->launches++;
     if (!async) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return CRT_OK;
 }
@@ -477,10 +491,29 @@ int crt_render_pass_counted(crt_ctx* ctx, int pass_id, int samples) {
 
 int crt_last_kernel_ms(crt_ctx* ctx, float* ms) {
     if (!ctx || !ms) return CRT_E_INVALID;
-    if (!ctx->timed) return fail(ctx, CRT_E_INVALID, "no render pass has been launched");
+    if (!ctx->launches) return fail(ctx, CRT_E_INVALID, "no render pass has been launched");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    const int slot = (int)((ctx->launches - 1) % crt_ctx::kRing);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1[slot]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0[slot], ctx->ev1[slot]));
+    return CRT_OK;
+}
+
+int crt_kernel_times(crt_ctx* ctx, float* ms, uint32_t cap, uint32_t* count) {
+    if (!ctx || !count || (cap && !ms)) return CRT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint64_t first = ctx->reported;
+    if (ctx->launches - first > (uint64_t)crt_ctx::kRing) first = ctx->launches - crt_ctx::kRing;
+    uint32_t n = 0;
+    for (uint64_t i = first; i < ctx->launches; i++, n++) {
+        const int slot = (int)(i % crt_ctx::kRing);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1[slot]));
+        float t = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev0[slot], ctx->ev1[slot]));
+        if (n < cap) ms[n] = t;
+    }
+    ctx->reported = ctx->launches;
+    *count = n;
     return CRT_OK;
 }
 

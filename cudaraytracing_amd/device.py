@@ -29,8 +29,11 @@ class Context:
     def set_partition(self, part, parts, strip_rows=16):
         self._check(capi.lib().crt_set_partition(self._h, part, parts, strip_rows))
 
-    def clear(self):
-        self._check(capi.lib().crt_clear(self._h))
+    def clear(self, stream=None, wait=True):
+        if wait and not stream:
+            self._check(capi.lib().crt_clear(self._h))
+        else:
+            self._check(capi.lib().crt_clear_async(self._h, C.c_void_p(stream or 0)))
 
     def render_pass(self, pass_id, samples, stream=None, wait=True):
         self._check(capi.lib().crt_render_pass(self._h, pass_id, samples, C.c_void_p(stream or 0), 0 if wait else 1))
@@ -73,6 +76,13 @@ class Context:
         ms = C.c_float()
         self._check(capi.lib().crt_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def kernel_times(self):
+        """Durations (ms) of the trace-kernel launches since the previous call."""
+        buf = np.zeros(256, np.float32)
+        n = C.c_uint32()
+        self._check(capi.lib().crt_kernel_times(self._h, capi.np_ptr(buf), 256, C.byref(n)))
+        return buf[:min(int(n.value), 256)].copy()
 
     def rng_selftest(self, seeds, subsequences, draws):
         seeds = np.ascontiguousarray(seeds, np.uint32)

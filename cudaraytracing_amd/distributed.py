@@ -1,0 +1,40 @@
+"""Image-space partition across GPUs and the one exchange step of a frame.
+
+Pixels are independent (one lane per pixel, seed = global pixel index), so every
+rank renders the 16-row strips it owns (strip s belongs to rank s % world) with the
+scene replicated, and the only communication is one gather of the owned rows to
+rank 0 (RCCL over xGMI when the tensors live on GPUs, gloo on CPU).  No reduction is
+involved: the gathered image is bit-identical to a single-GPU render."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def owned_rows(part, parts, height, strip_rows=16):
+    """Row indices of the image that `part` of `parts` renders."""
+    rows = np.arange(height)
+    return rows[(rows // strip_rows) % parts == part]
+
+
+def gather_rows(local, part, parts, strip_rows=16, dst=0, group=None):
+    """Gather the owned rows of every rank's (H, W, C) tensor to rank `dst`.
+
+    `local` holds valid data in the rows this rank owns.  Returns the assembled
+    (H, W, C) tensor on `dst` and None elsewhere.  With parts == 1 returns `local`."""
+    if parts == 1:
+        return local
+    H = local.shape[0]
+    idx = [torch.as_tensor(owned_rows(p, parts, H, strip_rows), device=local.device, dtype=torch.long) for p in range(parts)]
+    max_rows = max(int(i.numel()) for i in idx)
+    packed = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    mine = idx[part]
+    packed[: mine.numel()] = local.index_select(0, mine)
+    if part == dst:
+        bufs = [torch.empty_like(packed) for _ in range(parts)]
+        dist.gather(packed, gather_list=bufs, dst=dst, group=group)
+        out = torch.empty_like(local)
+        for p in range(parts):
+            out.index_copy_(0, idx[p], bufs[p][: idx[p].numel()])
+        return out
+    dist.gather(packed, gather_list=None, dst=dst, group=group)
+    return None

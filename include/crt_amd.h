@@ -191,8 +191,11 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* scene);
  * the whole image.  Pixels outside the part are never touched. */
 int crt_set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_rows);
 
-/* Zero the accumulators. */
+/* Zero the accumulators and the work counters (blocking). */
 int crt_clear(crt_ctx* ctx);
+
+/* Same, enqueued on `stream` (a hipStream_t) without waiting. */
+int crt_clear_async(crt_ctx* ctx, void* stream);
 
 /* One pass of the trace kernel: TracePrimaryRays<<<...>>>(pass_id)
  * (renderer/trace.cu:7-41, launch at renderer/renderer.cu:44) with `samples`
@@ -258,7 +261,7 @@ int crt_rng_selftest(crt_ctx* ctx, const uint32_t* seeds, const uint32_t* subseq
                      uint32_t n, uint32_t draws, uint32_t* out);
 
 /* Parity hook for the pinned transcendentals: evaluate function `fn`
- * (0 sin, 1 cos, 2 exp, 3 pow(x,y), 4 atan2(x=y arg,y=x arg), 5 asin, 6 acos)
+ * (0 sin, 1 cos, 2 exp, 3 pow(x, y), 4 atan2(x, y), 5 asin, 6 acos, 7 tan)
  * on n host floats on the GPU. */
 int crt_math_selftest(crt_ctx* ctx, int fn, const float* x, const float* y, uint32_t n,
                       float* out);
@@ -266,6 +269,12 @@ int crt_math_selftest(crt_ctx* ctx, int fn, const float* x, const float* y, uint
 /* Milliseconds the most recent crt_render_pass kernel took, measured with HIP
  * events on its stream (blocks until it has finished). */
 int crt_last_kernel_ms(crt_ctx* ctx, float* ms);
+
+/* Durations of the trace-kernel launches since the previous call of this
+ * function (at most 256 are kept, oldest first), each measured with a HIP event
+ * pair on the launch's own stream.  Blocks until those launches have finished.
+ * Writes min(*count, cap) values to ms and the number of launches to *count. */
+int crt_kernel_times(crt_ctx* ctx, float* ms, uint32_t cap, uint32_t* count);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,273 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Integer / index outputs (hit ids, ray counts, 8-bit image) and - because both sides use the
+same pinned transcendentals and no fused multiply-add - the float accumulators are compared
+bit for bit.  Against the glibc flavour of the oracle (what a host build of the reference
+computes) the tolerance is PSNR >= 35 dB on the 8-bit image at equal seeds and spp."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, scene_path
+import oracle_lib as orc
+
+import cudaraytracing_amd as crt
+from cudaraytracing_amd.distributed import owned_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+def load_both(name, w, h, flavour="det"):
+    s = crt.Scene.load_file(scene_path(name))
+    s.set_resolution(w, h)
+    o = orc.OracleScene(scene_path(name), flavour)
+    o.set_resolution(w, h)
+    return s, o
+
+
+def test_pinned_math_is_bit_identical_on_device(gpu_ctx):
+    rs = np.random.RandomState(11)
+    n = 1 << 18
+    x = rs.rand(n).astype(np.float32)
+    special = np.array([0, -0.0, 1, -1, np.inf, -np.inf, np.nan, 1e-45, 3.4e38, -3.4e38, 0.5, 2, 88.7, -104, 1e9], np.float32)
+    cases = [(0, x * 7 - 0.5, None), (1, x * 7 - 0.5, None), (2, (x - 0.5) * 220, None),
+             (3, x * 1.5 - 0.25, rs.choice(np.array([1024, 20, 0.41666, 5, 2, 1 / 21, 100, 33, 0, -3, 21], np.float32), n)),
+             (4, (x - 0.5) * 4, (rs.rand(n).astype(np.float32) - 0.5) * 4), (5, x * 2.2 - 1.1, None), (6, x * 2.2 - 1.1, None), (7, (x - 0.5) * 3, None)]
+    for fn, a, b in cases:
+        a = np.concatenate([a, special]).astype(np.float32)
+        b = None if b is None else np.concatenate([b, special[::-1]]).astype(np.float32)
+        g = gpu_ctx.math_selftest(fn, a, b)
+        c = orc.math(fn, a, b)
+        nan_both = np.isnan(g) & np.isnan(c)
+        assert np.array_equal(g.view(np.uint32)[~nan_both], c.view(np.uint32)[~nan_both]), fn
+
+
+def test_seeded_sequence_matches(gpu_ctx):
+    k = np.load(os.path.join(GOLDEN, "xorwow_kat.npz"))
+    assert np.array_equal(gpu_ctx.rng_selftest(k["seeds"], k["subsequences"], 8), k["words"])
+    rs = np.random.RandomState(5)
+    seeds = rs.randint(0, 1 << 31, 512).astype(np.uint32)
+    subs = rs.randint(0, 300, 512).astype(np.uint32)
+    assert np.array_equal(gpu_ctx.rng_selftest(seeds, subs, 16), orc.xorwow(seeds, subs, 16))
+
+
+@pytest.mark.parametrize("name", ["proj1_ball", "proj1_snowman", "proj5_box", "final_frame0042"])
+def test_primary_hits_equal_golden(gpu_ctx, name):
+    g = np.load(os.path.join(GOLDEN, f"primary_{name}_160x90.npz"))
+    s = crt.Scene.load_file(scene_path(name))
+    s.set_resolution(160, 90)
+    gpu_ctx.upload(s)
+    node, face, t = gpu_ctx.primary_hits(0)
+    assert np.array_equal(node, g["node"].astype(np.int32))
+    assert np.array_equal(face, g["face"])
+    assert np.array_equal(t.view(np.uint32), g["t_bits"])
+
+
+@pytest.mark.parametrize("name,w,h", [("proj1_ball", 1280, 720), ("proj5_glasspot", 640, 360), ("final_frame0001", 640, 360),
+                                      ("proj7_checkerboard", 640, 360), ("final_frame0042", 640, 360)])
+def test_primary_hits_equal_oracle(gpu_ctx, name, w, h):
+    """BASELINE config 1 (proj1 sphere scene, primary rays, scene resolution) and the mesh scenes."""
+    s, o = load_both(name, w, h)
+    gpu_ctx.upload(s)
+    for p in (0, 3):
+        node, face, t = gpu_ctx.primary_hits(p)
+        onode, oface, ot = o.primary_hits(p)
+        assert np.array_equal(node, onode) and np.array_equal(face, oface)
+        assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,spp", [("proj13_box", 1), ("final_frame0042", 2), ("proj7_checkerboard", 2)])
+def test_accumulators_equal_golden(gpu_ctx, name, spp):
+    g = np.load(os.path.join(GOLDEN, f"accum_{name}_64x36.npz"))
+    s = crt.Scene.load_file(scene_path(name))
+    s.set_resolution(64, 36)
+    gpu_ctx.upload(s)
+    gpu_ctx.render_pass(0, spp)
+    gpu_ctx.render_pass(1, spp)
+    acc = gpu_ctx.read_accumulators()
+    for k, n in enumerate(("results", "normals", "albedos")):
+        assert same(acc[k], g[n]), n
+    gpu_ctx.convert(0.5, s.srgb)
+    assert np.array_equal(gpu_ctx.read_image(), g["rgb"])
+
+
+CASES = [
+    ("proj4_box", 320, 180, 4),            # spheres, ambient + point light, refraction
+    ("teapot_low_box", 1280, 720, 1),      # BASELINE config 2: teapot-low BVH, shadows, 1 spp, scene resolution
+    ("proj5_box", 320, 180, 4),            # two teapot.obj instances, NEE through a mesh
+    ("proj5_glasspot", 256, 144, 2),       # 86 nodes, hollow teapot, nested transforms
+    ("proj7_checkerboard", 320, 180, 16),  # BASELINE config 3 at reduced size: textures, glossy + refractive, 16 spp
+    ("proj13_box", 320, 180, 4),
+    ("final_frame0001", 256, 144, 2),
+    ("final_frame0042", 320, 180, 4),      # BASELINE config 4 scene: 20 meshes, dof, sRGB
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp", CASES)
+def test_render_is_bit_exact(gpu_ctx, name, w, h, spp):
+    s, o = load_both(name, w, h)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, spp)
+    acc = gpu_ctx.read_accumulators()
+    ref, cnt = o.render(0, spp, count=True)
+    for k, n in enumerate(("results", "normals", "albedos")):
+        assert same(acc[k], ref[k]), (name, n)
+    st = gpu_ctx.stats()
+    assert (st["closest_rays"], st["shadow_rays"]) == (cnt["closest_rays"], cnt["shadow_rays"])
+    gpu_ctx.convert(1.0, s.srgb)
+    assert np.array_equal(gpu_ctx.read_image(), orc.convert(ref[0], o.srgb, 1.0))
+
+
+def test_counted_kernel_matches_oracle_counters(gpu_ctx):
+    s, o = load_both("final_frame0042", 192, 108)
+    gpu_ctx.upload(s)
+    gpu_ctx.render_pass_counted(0, 2)
+    acc = gpu_ctx.read_accumulators()
+    ref, cnt = o.render(0, 2, count=True)
+    assert same(acc[0], ref[0])
+    assert gpu_ctx.stats() == cnt
+
+
+def test_passes_accumulate_like_the_reference_loop(gpu_ctx):
+    """PASSES > 1: pass p uses subsequence p of every pixel's stream and adds into the buffers;
+    the displayed image divides by the passes so far (renderer/renderer.cu:39-61)."""
+    s, o = load_both("final_frame0042", 160, 90)
+    gpu_ctx.upload(s)
+    ref = o.new_accumulators()
+    for p in range(3):
+        gpu_ctx.render_pass(p, 2)
+        o.render(p, 2, acc=ref)
+        gpu_ctx.convert(1.0 / np.float32(p + 1), s.srgb)
+        assert np.array_equal(gpu_ctx.read_image(), orc.convert(ref[0], o.srgb, 1.0 / np.float32(p + 1))), p
+    assert same(gpu_ctx.read_accumulators()[0], ref[0])
+    # a large pass number exercises a multi-digit jump
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(77, 1)
+    assert same(gpu_ctx.read_accumulators()[0], o.render(77, 1)[0])
+
+
+def test_partition_reproduces_the_whole_image(gpu_ctx):
+    s, o = load_both("teapot_low_box", 200, 75)       # ragged: 75 rows, 200 = 25 tiles
+    gpu_ctx.upload(s)
+    gpu_ctx.render_pass(0, 2)
+    whole = gpu_ctx.read_accumulators()[0]
+    assert same(whole, o.render(0, 2)[0])
+    merged = np.zeros_like(whole)
+    for parts in (2, 3):
+        merged[:] = 0
+        for part in range(parts):
+            gpu_ctx.set_partition(part, parts, 16)
+            gpu_ctx.clear()
+            gpu_ctx.render_pass(0, 2)
+            acc = gpu_ctx.read_accumulators()[0]
+            rows = owned_rows(part, parts, 75)
+            others = np.setdiff1d(np.arange(75), rows)
+            assert not acc[others].any()          # rows of other parts are never touched
+            merged[rows] = acc[rows]
+        assert same(merged, whole)
+    gpu_ctx.set_partition(0, 1, 16)
+
+
+def test_edge_sizes(gpu_ctx):
+    for w, h in ((1, 1), (7, 3), (9, 17), (64, 8), (65, 9)):
+        s, o = load_both("proj4_box", w, h)
+        gpu_ctx.upload(s)
+        gpu_ctx.render_pass(0, 3)
+        assert same(gpu_ctx.read_accumulators()[0], o.render(0, 3, threads=1)[0]), (w, h)
+    # a scene whose only object is missed by every ray, and a light-less scene
+    s, o = load_both("proj1_ball", 32, 18)
+    gpu_ctx.upload(s)
+    gpu_ctx.render_pass(0, 2)
+    assert same(gpu_ctx.read_accumulators()[0], o.render(0, 2)[0])
+
+
+def test_tolerance_against_glibc_flavour(gpu_ctx):
+    """Against the oracle built on glibc's libm (what a host build of the reference computes):
+    PSNR of the 8-bit image >= 35 dB and >= 90 % of the pixels identical, at equal seeds and spp."""
+    for name, spp in (("final_frame0042", 8), ("proj7_checkerboard", 16), ("proj5_box", 8)):
+        s, o = load_both(name, 320, 180, "glibc")
+        gpu_ctx.upload(s)
+        gpu_ctx.clear()
+        gpu_ctx.render_pass(0, spp)
+        gpu_ctx.convert(1.0, s.srgb)
+        img = gpu_ctx.read_image()
+        ref = orc.convert(o.render(0, spp)[0], o.srgb, 1.0, "glibc")
+        assert psnr(img, ref) >= 35.0, (name, psnr(img, ref))
+        assert np.mean((img == ref).all(axis=2)) >= 0.90, name
+
+
+def test_full_size_frame_properties(gpu_ctx):
+    """BASELINE config 4 at full size (frame0042, 1920x1080): strips checked against the oracle,
+    the whole frame through size-independent properties."""
+    s, o = load_both("final_frame0042", 1920, 1080)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, 4)
+    acc = gpu_ctx.read_accumulators()
+    st = gpu_ctx.stats()
+    ref = o.new_accumulators()
+    for y0 in (0, 528, 1072):
+        o.render(0, 4, acc=ref, rows=(y0, y0 + 8))
+        for k in range(3):
+            assert same(acc[k][y0:y0 + 8], ref[k][y0:y0 + 8]), (y0, k)
+    # properties: one closest ray per path at least, shadow rays never exceed closest rays,
+    # normals AOV has length <= 1, radiance finite and non-negative, determinism across runs
+    assert st["closest_rays"] >= 1920 * 1080 * 4 and st["shadow_rays"] <= st["closest_rays"]
+    assert np.isfinite(acc[0]).all() and (acc[0] >= 0).all()
+    assert (np.linalg.norm(acc[1], axis=2) <= 1.0 + 1e-4).all()
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, 4)
+    assert same(gpu_ctx.read_accumulators()[0], acc[0])
+    assert gpu_ctx.stats() == st
+
+
+def test_errors_through_the_abi(gpu_ctx):
+    import ctypes
+    from cudaraytracing_amd import _capi as capi
+    fresh = crt.Context(0)
+    with pytest.raises(crt.CrtError) as e:
+        fresh.render_pass(0, 1)
+    assert e.value.code == capi.E_NOSCENE
+    s = crt.Scene.load_file(scene_path("proj4_box"))
+    s.set_resolution(16, 16)
+    fresh.upload(s)
+    for bad in ((-1, 1), (0, 0)):
+        with pytest.raises(crt.CrtError) as e:
+            fresh.render_pass(*bad)
+        assert e.value.code == capi.E_INVALID
+    with pytest.raises(crt.CrtError):
+        fresh.set_partition(2, 2, 16)
+    with pytest.raises(crt.CrtError):
+        fresh.set_partition(0, 2, 12)
+    d = s.desc()
+    d.env_texture = 999
+    assert capi.lib().crt_upload_scene(fresh._h, ctypes.byref(d)) == capi.E_INVALID
+    fresh.close()
+
+
+def test_renderer_front_end(gpu_ctx, tmp_path):
+    """The Renderer mirror (LoadScene / BeginRendering / GetImage / SaveImage) end to end."""
+    r = crt.Renderer(samples=2, passes=2, width=160, height=90)
+    assert not r.LoadScene("/nonexistent.xml")
+    assert r.LoadScene(scene_path("final_frame0042"))
+    r.BeginRendering(wait=True)
+    img = r.GetImage()
+    assert not r.IsRendering() and img.passes == 3 and (img.width, img.height) == (160, 90)
+    o = orc.OracleScene(scene_path("final_frame0042"))
+    o.set_resolution(160, 90)
+    ref = o.render(1, 2, acc=o.render(0, 2))
+    assert np.array_equal(img.pixels, orc.convert(ref[0], o.srgb, 0.5))
+    assert img.SaveImage(tmp_path / "out.png")
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "out.png")), img.pixels)
