@@ -136,7 +136,11 @@ def test_counted_kernel_matches_oracle_counters(gpu_ctx):
     acc = gpu_ctx.read_accumulators()
     ref, cnt = o.render(0, 2, count=True)
     assert same(acc[0], ref[0])
-    assert gpu_ctx.stats() == cnt
+    st = gpu_ctx.stats()
+    # the kernel evaluates each material texture once per path segment while the reference (and the oracle's
+    # counter) evaluates the same texels up to three times, so that one counter is only bounded
+    assert 0 < st.pop("texel_quads") <= cnt.pop("texel_quads")
+    assert st == cnt
 
 
 def test_passes_accumulate_like_the_reference_loop(gpu_ctx):
