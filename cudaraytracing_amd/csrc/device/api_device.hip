@@ -410,11 +410,11 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // two LDS arrays (node reference, entry distance) of stack_entries x 256 words
     ctx->lds_bytes = (size_t)S.stack_entries * CRT_BLOCK * 4 * 2;
     if (ctx->lds_bytes > 160 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)primary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, render_kernel<false>, CRT_BLOCK, ctx->lds_bytes));
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, render_kernel<true>, CRT_BLOCK, ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, (trace_kernel<false, false>), CRT_BLOCK, ctx->lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, (trace_kernel<true, false>), CRT_BLOCK, ctx->lds_bytes));
     if (ctx->blocks_per_cu < 1) ctx->blocks_per_cu = 1;
     if (ctx->blocks_per_cu_counted < 1) ctx->blocks_per_cu_counted = 1;
 
@@ -471,9 +471,9 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     const int slot = (int)(ctx->launches % crt_ctx::kRing);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], stream));
     if (counted)
-        hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats);
+        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
     else
-        hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats);
+        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], stream));
     ctx->launches++;
@@ -578,8 +578,12 @@ int crt_primary_hits(crt_ctx* ctx, int pass_id, int32_t* node, int32_t* face, fl
     HIP_TRY(ctx, hipMemset(d_face, 0xff, px * 4));
     HIP_TRY(ctx, hipMemset(d_t, 0, px * 4));
     if (ctx->P.total_items) {
-        hipLaunchKernelGGL(primary_kernel, dim3((ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK), dim3(CRT_BLOCK), ctx->lds_bytes, nullptr,
-                           ctx->S, ctx->P, jump, d_node, d_face, d_t);
+        HIP_TRY(ctx, hipMemset(ctx->queue, 0, 4));
+        uint32_t grid = (uint32_t)(ctx->num_cus * ctx->blocks_per_cu);
+        const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
+        if (grid > need) grid = need;
+        hipLaunchKernelGGL((trace_kernel<false, true>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, nullptr,
+                           ctx->S, ctx->P, 1, jump, ctx->queue, ctx->stats, d_node, d_face, d_t);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipDeviceSynchronize());

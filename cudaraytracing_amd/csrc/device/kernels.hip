@@ -1,19 +1,23 @@
 // gfx950 kernels of the per-pixel trace path.
 //
-// render_kernel replaces TracePrimaryRays (renderer/trace.cu:7-41) and every
+// trace_kernel replaces TracePrimaryRays (renderer/trace.cu:7-41) and every
 // device function it reaches.  It is a persistent kernel: each lane owns one
 // pixel at a time, runs that pixel's samples one after another (they share one
 // random stream, renderer/trace.cu:22-25) and, when the pixel is finished,
 // takes the next unowned pixel from a global queue with one wave-aggregated
 // atomic (ballot + mbcnt prefix), so lanes do not idle on short pixels.
 //
-// Inside a ray query the lanes of a wave are generally at different scene
-// nodes and in different mesh BVHs.  Both the linear scene-node scan and the
-// BVH descent are therefore expressed as the same step - "fetch one 64-byte
-// box-pair record, slab-test two boxes against my current ray" - so that all
-// 64 lanes execute the expensive part together whatever phase each one is in.
-// The per-lane traversal stack lives in LDS, laid out [entry][thread] so that
-// any mix of stack depths is bank-conflict free.
+// The work of a pixel is cut into small operations - slab-test one 64-byte
+// box-pair record (scene-node scan and BVH descent are the same operation),
+// test one triangle, enter a node, leave a mesh, shade, start a path, fetch a
+// pixel - and every lane carries the operation it needs next.  Each turn of
+// the main loop the wave votes (ballot + popcount) and executes only the
+// operation most lanes are waiting for, so a lane in a rare phase does not
+// make the other 63 walk through its code; closest-hit and shadow queries
+// share the box and triangle operations.  The order of operations of any one
+// pixel is exactly the reference's, only their interleaving across lanes is
+// scheduled.  The per-lane traversal stack lives in LDS, laid out
+// [entry][thread] so that any mix of stack depths is bank-conflict free.
 //
 // Arithmetic keeps the reference's operation order (see crt_vec.h); the file is
 // compiled with -ffp-contract=off and uses the pinned transcendentals of
@@ -89,15 +93,6 @@ struct Tally {
     uint32_t node_box_tests, node_enters, bvh_interior, bvh_leaves, tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
 };
 #define TALLY(field) do { if (kCount) tally.field++; } while (0)
-
-// ------------------------------------------------------------------ hit record (scene/rays.cuh:20-61)
-struct HitRec {
-    f3 pos; float z; f3 n; f3 uvw;
-    bool front;
-    int node;        // hit scene node
-    int light;       // >= 0: the hit is on this light
-    int face;        // face index for mesh hits
-};
 
 DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
@@ -197,345 +192,6 @@ DEV f3 glossy_normal(f3 normal, float glossiness, Rng& rng) {
     return normal * cos_theta + u * sin_theta * cos_phi + v * sin_theta * sin_phi;
 }
 
-// ------------------------------------------------------------------ primitives (scene/objects.cu:7-159)
-DEV void sphere_uvw(f3 p, f3& uvw) {
-    uvw = mk3(0.5f * 0.318309f * crtm::det_atan2f(p.y, p.x) + 0.5f,
-              0.318309f * crtm::det_asinf(fminf(fmaxf(p.z, -1.0f), 1.0f)) + 0.5f, 0);
-}
-
-// unit sphere, local space; both sides accepted (the reference always passes FRONT_AND_BACK)
-DEV bool sphere_closest(f3 pos, f3 dir, HitRec& hit) {
-    if (dot(dir, pos) >= 0) return false;
-    const float a = dot(dir, dir);
-    const float b = dot(dir, pos) * 2;
-    const float c = dot(pos, pos) - 1;
-    const float det = b * b - 4 * a * c;
-    if (det < 0) return false;
-    const float sq = sqrtf(det);
-    const float front = (-b - sq) / (2 * a);
-    const float back = (-b + sq) / (2 * a);
-    if (front >= 0) {
-        if (front >= hit.z) return false;
-        hit.z = front;
-        hit.pos = pos + front * dir;
-        hit.n = hit.pos;
-        sphere_uvw(hit.pos, hit.uvw);
-        hit.front = true; hit.light = -1; hit.face = -1;
-        return true;
-    }
-    if (back < 0) return false;
-    if (back >= hit.z) return false;
-    hit.z = back;
-    hit.pos = pos + back * dir;
-    hit.n = hit.pos;
-    sphere_uvw(hit.pos, hit.uvw);
-    hit.front = false; hit.light = -1; hit.face = -1;
-    return true;
-}
-
-DEV bool sphere_shadow(f3 pos, f3 dir, float tMax) {
-    if (dot(dir, pos) >= 0) return false;
-    const float a = dot(dir, dir);
-    const float b = dot(dir, pos) * 2;
-    const float c = dot(pos, pos) - 1;
-    const float det = b * b - 4 * a * c;
-    if (det < 0) return false;
-    const float sq = sqrtf(det);
-    const float front = (-b - sq) / (2 * a);
-    const float back = (-b + sq) / (2 * a);
-    if (front >= 0 && front <= tMax) return true;
-    if (back >= 0 && back <= tMax) return true;
-    return false;
-}
-
-DEV bool plane_closest(f3 pos, f3 dir, HitRec& hit) {
-    if (dir.z == 0) return false;
-    const float t = -pos.z / dir.z;
-    if (t < 0 || t >= hit.z) return false;
-    if (!(dir.z < 0) && !(dir.z > 0)) return false;
-    const f3 p = pos + t * dir;
-    if (fabsf(p.x) > 1 || fabsf(p.y) > 1) return false;
-    hit.z = t;
-    hit.pos = p;
-    hit.n = mk3(0, 0, 1);
-    hit.uvw = 0.5f * (p + mk3(1, 1, 0));
-    hit.front = dir.z < 0;
-    hit.light = -1; hit.face = -1;
-    return true;
-}
-
-DEV bool plane_shadow(f3 pos, f3 dir, float tMax) {
-    if (dir.z == 0) return false;
-    const float t = -pos.z / dir.z;
-    if (t < 0 || t >= tMax) return false;
-    if (!(dir.z < 0) && !(dir.z > 0)) return false;
-    const f3 p = pos + t * dir;
-    if (fabsf(p.x) > 1 || fabsf(p.y) > 1) return false;
-    return true;
-}
-
-// PointLight::Intersect (scene/lights.cu:36-89), world space
-DEV bool light_intersect(const DevLight& L, f3 rpos, f3 rdir, HitRec& hit) {
-    const f3 lp = ld3(L.pos);
-    const f3 o = rpos - lp;
-    const float a = dot(rdir, rdir);
-    const float b = dot(2 * rdir, o);
-    const float c = dot(o, o) - L.size * L.size;
-    const float det = b * b - 4 * a * c;
-    if (det < 0) return false;
-    const float sq = sqrtf(det);
-    const float front = (-b - sq) / (2 * a);
-    const float back = (-b + sq) / (2 * a);
-    const float overpi = (float)(1.0f / 3.14159265358979323846);
-    if (front >= 0) {
-        if (front >= hit.z) return false;
-        hit.z = front;
-        const f3 np = normalized(o);
-        hit.pos = rpos + front * rdir;
-        hit.n = np;
-        hit.uvw = mk3(0.5f * overpi * crtm::det_atan2f(np.y, np.x) + 0.5f,
-                      overpi * crtm::det_asinf(fminf(fmaxf(np.z, -1.0f), 1.0f)) + 0.5f, 0);
-        hit.front = true;
-        return true;
-    }
-    if (back < 0) return false;
-    if (back >= hit.z) return false;
-    hit.z = back;
-    const f3 np = normalized(hit.pos);      // the previous hit position, as the reference reads it (lights.cu:78)
-    hit.pos = rpos + back * rdir;
-    hit.uvw = mk3(0.5f * overpi * crtm::det_atan2f(np.y, np.x) + 0.5f,
-                  overpi * crtm::det_asinf(fminf(fmaxf(np.z, -1.0f), 1.0f)) + 0.5f, 0);
-    hit.n = np;
-    hit.front = false;
-    return true;
-}
-
-// ------------------------------------------------------------------ scene traversal
-// One function for both query kinds:
-//   kShadow == false : TraceThroughScene (renderer/trace.cu:44-81) + MeshObject::Traverse
-//                      (scene/objects.cu:173-222) + IntersectTriangle (270-324)
-//   kShadow == true  : TraceShadowRay (renderer/trace.cu:160-196) + TraverseShadow (224-268)
-//                      + IntersectShadowTriangle (326-366); returns true when occluded.
-// rpos / rdir are the ray in world space and are transformed in place into and
-// out of every entered node, as the reference does.  The caller has applied the bias.
-template <bool kShadow, bool kCount>
-DEV bool trace_scene(const DevScene& S, f3& rpos, f3& rdir, float tMax, HitRec& hit,
-                     uint32_t* __restrict__ stack_ref, float* __restrict__ stack_t, Tally& tally) {
-    const BoxPair* __restrict__ pairs = S.pairs;
-    const TriRec* __restrict__ tris = S.tris;
-    const uint32_t node_count = S.node_count;
-    const uint32_t tid = threadIdx.x;
-
-    bool any = false;
-    uint32_t node = 0;            // next scene node to look at (scan mode)
-    bool trav = false;            // inside a mesh BVH
-    uint32_t cur = 0;             // interior BVH record to expand (trav mode)
-    uint32_t sp = 0;              // LDS stack height
-    uint32_t entered = 0;         // scene node being traversed
-    f3 inv = recip3(rdir);
-    // pending closest hit on the mesh being traversed
-    bool mesh_hit = false, mesh_front = false;
-    uint32_t mesh_slot = 0;
-    float mesh_b1 = 0, mesh_b2 = 0;
-
-    while (node < node_count || trav) {
-        // ---- the common step: one record, two slab tests
-        const uint32_t rec_idx = trav ? cur : node;
-        const float4* rp = reinterpret_cast<const float4*>(pairs + rec_idx);
-        const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-        const float a_min[3] = {q0.x, q0.y, q0.z}, a_max[3] = {q0.w, q1.x, q1.y};
-        const float b_min[3] = {q1.z, q1.w, q2.x}, b_max[3] = {q2.y, q2.z, q2.w};
-        const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
-        const float limit = kShadow ? tMax : CRT_BIGFLOAT;
-        float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
-        float dA, dB;
-        const bool hitA = slab(a_min, a_max, rpos, inv, limit, dA);
-        const bool hitB = slab(b_min, b_max, rpos, inv, limit, dB);
-        if (hitA) tA = dA;
-        if (hitB) tB = dB;
-
-        bool resolve = false;           // run the stack-resolve loop below
-        bool have_next = false;
-        uint32_t next_ref = 0;
-        float next_t = 0;
-
-        if (trav) {
-            TALLY(bvh_interior);
-            if (hitA || hitB) {
-                const bool a_near = tA <= tB;
-                const uint32_t far_ref = a_near ? ref_b : ref_a;
-                stack_ref[sp * CRT_BLOCK + tid] = far_ref;
-                if (!kShadow) stack_t[sp * CRT_BLOCK + tid] = fmaxf(tA, tB);
-                sp++;
-                next_ref = a_near ? ref_a : ref_b;
-                next_t = fminf(tA, tB);
-                have_next = true;
-            }
-            resolve = true;
-        } else {
-            // ---- scan mode: node `node` is half A, node + 1 is half B
-            uint32_t enter_node = kRefNone;
-            uint32_t enter_kind = 0;
-            uint32_t nxt;
-            const uint32_t kind_a = node_ref_kind(ref_a);
-            bool a_entered = false;
-            nxt = node + 1;
-            if (kind_a != CRT_OBJ_NONE) {
-                TALLY(node_box_tests);
-                if (kShadow) {
-                    if (hitA) { a_entered = true; }
-                    else nxt = node_ref_after(ref_a);           // skip the subtree (trace.cu:171-185)
-                } else if (hitA && tA < hit.z) a_entered = true;
-            }
-            if (a_entered) { enter_node = node; enter_kind = kind_a; }
-            else if (nxt == node + 1 && nxt < node_count) {
-                const uint32_t kind_b = node_ref_kind(ref_b);
-                nxt = node + 2;
-                if (kind_b != CRT_OBJ_NONE) {
-                    TALLY(node_box_tests);
-                    if (kShadow) {
-                        if (hitB) { enter_node = node + 1; enter_kind = kind_b; }
-                        else nxt = node_ref_after(ref_b);
-                    } else if (hitB && tB < hit.z) { enter_node = node + 1; enter_kind = kind_b; }
-                }
-            }
-            if (enter_node == kRefNone) {
-                node = nxt;
-            } else {
-                TALLY(node_enters);
-                const NodeXf* __restrict__ xf = S.xf + enter_node;
-                rpos = xform_point(xf->itm, rpos);
-                rdir = xform_dir(xf->itm, rdir);
-                if (enter_kind == CRT_OBJ_MESH) {
-                    inv = recip3(rdir);
-                    trav = true; entered = enter_node; sp = 0; mesh_hit = false;
-                    next_ref = xf->root_ref; next_t = 0; have_next = true;
-                    resolve = true;
-                } else {
-                    bool got;
-                    if (enter_kind == CRT_OBJ_SPHERE) {
-                        TALLY(sphere_tests);
-                        if (kShadow) got = sphere_shadow(rpos, rdir, tMax);
-                        else got = sphere_closest(rpos, rdir, hit);
-                    } else {
-                        TALLY(plane_tests);
-                        if (kShadow) got = plane_shadow(rpos, rdir, tMax);
-                        else got = plane_closest(rpos, rdir, hit);
-                    }
-                    if (got) {
-                        if (kShadow) return true;
-                        any = true;
-                        hit.pos = xform_point(xf->tm, hit.pos);
-                        hit.n = xform_normal(xf->itm, hit.n);
-                        hit.node = (int)enter_node;
-                    }
-                    rpos = xform_point(xf->tm, rpos);
-                    rdir = xform_dir(xf->tm, rdir);
-                    inv = recip3(rdir);
-                    node = enter_node + 1;
-                }
-            }
-        }
-
-        if (resolve) {
-            // pop until an interior node that survives the distance cull is found
-            bool finished = false;
-            for (;;) {
-                if (!have_next) {
-                    if (sp == 0) { finished = true; break; }
-                    sp--;
-                    next_ref = stack_ref[sp * CRT_BLOCK + tid];
-                    if (!kShadow) next_t = stack_t[sp * CRT_BLOCK + tid];
-                }
-                have_next = false;
-                if (!kShadow && hit.z < next_t) continue;
-                if (!ref_is_leaf(next_ref)) { cur = next_ref; break; }
-                TALLY(bvh_leaves);
-                const uint32_t t0 = leaf_start(next_ref), tn = leaf_count(next_ref);
-                for (uint32_t k = 0; k < tn; k++) {
-                    TALLY(tri_tests);
-                    const float4* tp = reinterpret_cast<const float4*>(tris + t0 + k);
-                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                    const f3 p0 = mk3(v0.x, v0.y, v0.z);
-                    const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
-                    const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
-                    const f3 rXe2 = cross(rdir, edge2);
-                    const float det = dot(edge1, rXe2);
-                    if (det > -CRT_TRI_EPS && det < CRT_TRI_EPS) continue;
-                    const float idet = 1 / det;
-                    const f3 offset = rpos - p0;
-                    const float b1 = idet * dot(offset, rXe2);
-                    if (b1 <= CRT_TRI_EPS || b1 >= 1 + CRT_TRI_EPS) continue;
-                    const f3 oXe1 = cross(offset, edge1);
-                    const float b2 = idet * dot(rdir, oXe1);
-                    if (b2 <= -CRT_TRI_EPS || (b1 + b2) >= 1 + CRT_TRI_EPS) continue;
-                    const float t = idet * dot(edge2, oXe1);
-                    const float far_limit = (kShadow ? tMax : hit.z) + CRT_TRI_EPS;
-                    if (t <= CRT_TRI_EPS || t >= far_limit) continue;
-                    const float ndot = dot(cross(edge1, edge2), rdir);
-                    if (!(ndot < CRT_TRI_EPS) && !(ndot > -CRT_TRI_EPS)) continue;
-                    if (kShadow) return true;
-                    TALLY(tri_hits);
-                    hit.z = t;
-                    mesh_hit = true; mesh_front = ndot < 0; mesh_slot = t0 + k; mesh_b1 = b1; mesh_b2 = b2;
-                }
-            }
-            if (finished) {
-                // leave the mesh: finish the hit (objects.cu:308-323), then Node::FromLocal for hit and ray
-                const NodeXf* __restrict__ xf = S.xf + entered;
-                if (!kShadow && mesh_hit) {
-                    const float4* tp = reinterpret_cast<const float4*>(tris + mesh_slot);
-                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                    const f3 p0 = mk3(v0.x, v0.y, v0.z);
-                    const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
-                    const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
-                    const uint32_t face = __float_as_uint(v0.w);
-                    const float b0 = 1 - mesh_b2 - mesh_b1;
-                    const DevMesh M = S.meshes[xf->mesh_id];
-                    f3 n, uvw;
-                    if (!M.has_normals) n = normalized(cross(edge1, edge2));
-                    else {
-                        const uint32_t i0 = M.fn[3 * face], i1 = M.fn[3 * face + 1], i2 = M.fn[3 * face + 2];
-                        n = ld3(M.vn + 3 * i0) * b0 + ld3(M.vn + 3 * i1) * mesh_b1 + ld3(M.vn + 3 * i2) * mesh_b2;
-                    }
-                    if (!M.has_tex) uvw = mk3(0, 0, 0);
-                    else {
-                        const uint32_t i0 = M.ft[3 * face], i1 = M.ft[3 * face + 1], i2 = M.ft[3 * face + 2];
-                        uvw = ld3(M.vt + 3 * i0) * b0 + ld3(M.vt + 3 * i1) * mesh_b1 + ld3(M.vt + 3 * i2) * mesh_b2;
-                    }
-                    any = true;
-                    hit.pos = xform_point(xf->tm, rpos + hit.z * rdir);
-                    hit.n = xform_normal(xf->itm, n);
-                    hit.uvw = uvw;
-                    hit.front = mesh_front;
-                    hit.light = -1;
-                    hit.face = (int)face;
-                    hit.node = (int)entered;
-                }
-                rpos = xform_point(xf->tm, rpos);
-                rdir = xform_dir(xf->tm, rdir);
-                inv = recip3(rdir);
-                trav = false;
-                node = entered + 1;
-            }
-        }
-    }
-
-    if (kShadow) return false;
-
-    // lights are tested last, against the ray as the node loop left it (trace.cu:72-78)
-    for (uint32_t i = 0; i < S.light_count; i++) {
-        const DevLight L = S.lights[i];
-        if (L.kind == CRT_LIGHT_POINT && light_intersect(L, rpos, rdir, hit)) { any = true; hit.light = (int)i; hit.face = -1; }
-    }
-    return any;
-}
-
-DEV void hit_init(HitRec& h) {
-    h.pos = mk3(0, 0, 0); h.z = CRT_BIGFLOAT; h.n = mk3(0, 1, 0); h.uvw = mk3(0, 0, 0);
-    h.front = true; h.node = -1; h.light = -1; h.face = -1;
-}
-
 // ------------------------------------------------------------------ camera (renderer/trace.cu:14-38)
 DEV void camera_ray(const DevScene& S, uint32_t pX, uint32_t pY, Rng& rng, f3& pos, f3& dir) {
     const f3 cX = ld3(S.cX), cY = ld3(S.cY);
@@ -574,236 +230,585 @@ DEV unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-// ------------------------------------------------------------------ the path tracer
-template <bool kCount>
-__global__ __launch_bounds__(CRT_BLOCK) void render_kernel(DevScene S, DevPartition P, int samples,
-                                                           const uint32_t* __restrict__ jump,
-                                                           uint32_t* __restrict__ queue, DevStats* __restrict__ stats) {
+// ------------------------------------------------------------------ per-lane state
+enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_ENTER = 2, S_EXIT = 3, S_SHADE = 4, S_CAMERA = 5, S_FETCH = 6, S_DONE = 7 };
+enum : uint32_t { H_NONE = 0, H_SPHERE = 1, H_PLANE = 2, H_MESH = 3 };
+
+struct Lane {
+    // pixel and path
+    Rng rng;
+    uint32_t pI;
+    int sample;
+    uint32_t segments;
+    f3 target, normal, albedo;      // the pixel's three accumulators (renderer/trace.cu:39)
+    f3 contrib;
+    f3 v;                           // -normalised direction of the current segment (trace.cu:86)
+    // current ray query (closest hit or shadow)
+    f3 qpos, qdir, qinv;            // ray in the space it is currently in, and 1/dir
+    float limit;                    // slab t_max: FLT_MAX for closest hit, the light distance for shadow rays
+    uint32_t node;                  // next scene node to scan
+    uint32_t cur;                   // BVH record to expand
+    uint32_t sp;                    // LDS stack height
+    uint32_t entered;               // scene node whose mesh is being traversed
+    uint32_t pend;                  // S_LEAF: remaining leaf range; S_ENTER: node | kind << 30
+    bool shadow, trav, mesh_hit;
+    // closest hit so far; normal / texture coordinates are derived from (h_*) when the query ends
+    float hz;
+    f3 hpos;                        // world space
+    uint32_t h_kind, h_node;
+    float h_a, h_b;                 // mesh: barycentrics b1, b2; sphere / plane: local hit x, y
+    uint32_t h_c;                   // mesh: triangle record; sphere / plane: bits of local hit z
+    bool h_front;
+    // the path while its shadow query runs
+    f3 ndir, nee;
+    bool nee_valid, path_alive;
+};
+
+// ------------------------------------------------------------------ the scheduled path tracer
+template <bool kCount, bool kPrimary>
+__global__ __launch_bounds__(CRT_BLOCK) void trace_kernel(DevScene S, DevPartition P, int samples,
+                                                          const uint32_t* __restrict__ jump,
+                                                          uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
+                                                          int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
+                                                          float* __restrict__ out_t) {
     extern __shared__ uint32_t lds[];
-    uint32_t* stack_ref = lds;
-    float* stack_t = reinterpret_cast<float*>(lds + S.stack_entries * CRT_BLOCK);
+    uint32_t* __restrict__ stack_ref = lds;
+    float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * CRT_BLOCK);
+    const uint32_t tid = threadIdx.x;
+    const BoxPair* __restrict__ pairs = S.pairs;
+    const TriRec* __restrict__ tris = S.tris;
+    const uint32_t node_count = S.node_count;
 
     Tally tally = {};
     const float F_PI = 3.14159265358979323846f;
     const float OVERPI = (float)(1.0f / 3.14159265358979323846);
     const float inv_samples = 1.0f / (float)samples;
 
-    bool have_pixel = false, queue_empty = false;
-    uint32_t pI = 0, pX = 0, pY = 0;
-    int sample = 0;
-    bool new_path = true;
-    Rng rng = {};
-    f3 target = mk3(0, 0, 0), normal = mk3(0, 0, 0), albedo = mk3(0, 0, 0);
-    f3 rpos = mk3(0, 0, 0), rdir = mk3(0, 0, 1), contrib = mk3(0, 0, 0);
-    uint32_t segments = 0;
+    Lane L = {};
+    uint32_t state = S_FETCH;
+    bool queue_empty = false;
 
-    for (;;) {
-        // ---- refill idle lanes from the pixel queue
-        if (!queue_empty) {
-            const bool need = !have_pixel;
-            const unsigned long long mask = __ballot(need);
-            if (mask) {
-                uint32_t base = 0;
-                const uint32_t cnt = (uint32_t)__popcll(mask);
-                if (lane_rank(mask) == 0 && need) base = atomicAdd(queue, cnt);
-                base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-                if (base >= P.total_items) queue_empty = true;      // uniform: every later item is past the end too
-                if (need) {
-                    const uint32_t item = base + lane_rank(mask);
-                    if (item < P.total_items && item_to_pixel(S, P, item, pX, pY)) {
-                        have_pixel = true;
-                        pI = pY * S.width + pX;
-                        rng_init(rng, pI, jump);
-                        target = ld3(S.results + 3ull * pI);
-                        normal = ld3(S.normals + 3ull * pI);
-                        albedo = ld3(S.albedos + 3ull * pI);
-                        sample = 0; new_path = true;
-                    }
-                }
+    // ---- transitions -----------------------------------------------------------------------
+    auto end_path = [&]() -> uint32_t {
+        if (++L.sample >= samples) {
+            if (!kPrimary) {
+                float* r = S.results + 3ull * L.pI;
+                float* nn = S.normals + 3ull * L.pI;
+                float* al = S.albedos + 3ull * L.pI;
+                r[0] = L.target.x; r[1] = L.target.y; r[2] = L.target.z;
+                nn[0] = L.normal.x; nn[1] = L.normal.y; nn[2] = L.normal.z;
+                al[0] = L.albedo.x; al[1] = L.albedo.y; al[2] = L.albedo.z;
             }
+            return S_FETCH;
         }
-        if (__ballot(have_pixel) == 0ull) {
-            if (queue_empty) break;
-            continue;
-        }
-        if (!have_pixel) continue;
-
-        // ---- one path segment (renderer/trace.cu:83-158)
-        if (new_path) {
-            camera_ray(S, pX, pY, rng, rpos, rdir);
-            contrib = mk3(1, 1, 1) * inv_samples;
-            new_path = false; segments = 0;
-            TALLY(paths);
-        }
-        bool path_done = false;
-        const f3 v = -normalized(rdir);
-        HitRec hit;
-        hit_init(hit);
+        return S_CAMERA;
+    };
+    // TraceThroughScene prologue (renderer/trace.cu:44-50); qpos / qdir hold the path ray
+    auto start_closest = [&]() -> uint32_t {
+        L.v = -normalized(L.qdir);
+        L.qpos += L.qdir * CRT_BIAS;
+        L.qinv = recip3(L.qdir);
+        L.limit = CRT_BIGFLOAT;
+        L.shadow = false; L.trav = false; L.node = 0;
+        L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
         tally.closest_rays++;
-        rpos += rdir * CRT_BIAS;
-        const bool any = trace_scene<false, kCount>(S, rpos, rdir, CRT_BIGFLOAT, hit, stack_ref, stack_t, tally);
-        if (!any) {
-            const f3 env = tex_env<kCount>(S, rdir, tally);
-            target += contrib * env;
-            normal += contrib * normalized(rdir);
-            albedo += contrib * env;
-            path_done = true;
-        } else if (hit.light >= 0) {
-            const f3 rad = ld3(S.lights[hit.light].radiance);
-            target += contrib * rad;
-            normal += contrib * hit.n;
-            albedo += contrib * rad;
-            path_done = true;
-        } else {
-            const float light_pick = rng_float(rng);
-            const DevMaterial mtl = S.materials[S.xf[hit.node].material_id];
-            const f3 kD = tex_eval<kCount>(S, mtl.diffuse, hit.uvw, tally);
-            const f3 kS = tex_eval<kCount>(S, mtl.specular, hit.uvw, tally);
-            const f3 kT = tex_eval<kCount>(S, mtl.refraction, hit.uvw, tally);
-            const f3 kE = tex_eval<kCount>(S, mtl.emission, hit.uvw, tally);
-            normal += contrib * hit.n;
-            albedo += contrib * kD + kE;
-            target += contrib * kE;
+        return S_BOX;
+    };
+    auto continue_path = [&]() -> uint32_t {
+        if (!L.path_alive) return end_path();
+        L.qpos = L.hpos;
+        L.qdir = L.ndir;
+        return start_closest();
+    };
+    // end of TraceShadowRay: add the light sample if nothing was in the way (trace.cu:137-143)
+    auto finish_shadow = [&](bool occluded) -> uint32_t {
+        if (!occluded && L.nee_valid) L.target += L.nee;
+        return continue_path();
+    };
+    auto finish_query = [&]() -> uint32_t { return L.shadow ? finish_shadow(false) : (uint32_t)S_SHADE; };
+    auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_BOX : finish_query(); };
 
-            // lobe probabilities (renderer/shading.cu:17-29 and 122-134)
-            const float third = 1.0f / 3.0f;
-            float pD = (kD.x + kD.y + kD.z) * third;
-            float pS = (kS.x + kS.y + kS.z) * third;
-            float pT = (kT.x + kT.y + kT.z) * third;
-            if (pD + pS + pT > CRT_MAX_SURVIVAL) {
-                const float norm = CRT_MAX_SURVIVAL / (pD + pS + pT);
-                pD *= norm; pS *= norm; pT *= norm;
+    // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
+    // (MeshObject::Traverse / TraverseShadow loop heads, scene/objects.cu:184-196, 231-242)
+    auto resolve = [&](bool have_next, uint32_t next_ref, float next_t) -> uint32_t {
+        for (;;) {
+            if (!have_next) {
+                if (L.sp == 0) return S_EXIT;
+                L.sp--;
+                next_ref = stack_ref[L.sp * CRT_BLOCK + tid];
+                next_t = stack_t[L.sp * CRT_BLOCK + tid];
             }
-            const float g = mtl.glossiness;
+            have_next = false;
+            if (!L.shadow && L.hz < next_t) continue;
+            if (!ref_is_leaf(next_ref)) { L.cur = next_ref; return S_BOX; }
+            TALLY(bvh_leaves);
+            if (leaf_count(next_ref) == 0) continue;
+            L.pend = next_ref;
+            return S_LEAF;
+        }
+    };
 
-            // next-event estimation toward one light (trace.cu:112-143).  Ambient and
-            // directional lights produce no sample and zero weight, so nothing is traced.
-            if (S.light_count > 0) {
-                const int light_id = crtm::f2i_sat(light_pick * (float)S.light_count);
-                const DevLight L = S.lights[light_id];
-                if (L.kind == CRT_LIGHT_POINT) {
-                    // PointLight::GenerateSample (scene/lights.cu:10-34)
-                    const f3 lp = ld3(L.pos);
-                    const f3 Ldir = normalized(hit.pos - lp);
-                    const float x = rng_float(rng);
-                    const float phi = rng_float(rng) * 2 * F_PI;
-                    const float cos_theta = 1 - x;
-                    const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-                    f3 a, b;
-                    orthonormals(Ldir, a, b);
-                    const f3 n = Ldir * cos_theta + a * sin_theta * crtm::det_cosf(phi) + b * sin_theta * crtm::det_sinf(phi);
-                    const f3 tgt = lp + n * L.size;
-                    const f3 ldir = normalized(tgt - hit.pos);
-                    const float d2 = lengthsq(tgt - hit.pos);
-                    const float cos_theta_l = dot(ldir, -normalized(tgt - lp));
-                    const float l_prob = d2 / (2 * F_PI * L.size * L.size * cos_theta_l);
-                    const f3 l_mult = ld3(L.radiance);
-                    const float l_dist = sqrtf(d2);
-                    // Material::GetSampleInfo (renderer/shading.cu:116-150)
-                    float b_prob = 0.0f;
-                    f3 b_mult = mk3(0, 0, 0);
-                    const float ndl = dot(hit.n, ldir);
-                    if (ndl >= 0) {
-                        b_prob += pD * (ndl > 0 ? OVERPI : 0);
-                        b_mult += kD * OVERPI * ndl;
-                        const f3 rn = normalized(v + ldir);
-                        const float ndh = dot(hit.n, rn);
-                        b_prob += pS * (g + 1) * 0.5f * OVERPI * crtm::det_powf(ndh, g + 1);
-                        b_mult += kS * (g + 2) * 0.125f * OVERPI * crtm::det_powf(ndh, g);
-                    }
-                    // TraceShadowRay (trace.cu:160-196)
-                    f3 spos = hit.pos, sdir = ldir;
-                    spos += sdir * CRT_BIAS + hit.n * CRT_BIAS;
-                    tally.shadow_rays++;
-                    HitRec dummy;
-                    dummy.z = CRT_BIGFLOAT;
-                    const bool occluded = trace_scene<true, kCount>(S, spos, sdir, l_dist, dummy, stack_ref, stack_t, tally);
-                    if (!occluded) {
-                        const float denom = l_prob * l_prob + b_prob * b_prob;
-                        if (denom > CRT_F_EPS && l_prob > CRT_F_EPS) {
-                            const float pop = l_prob / denom;
-                            target += contrib * l_mult * b_mult * pop;
-                        }
-                    }
+    // ---- operations ------------------------------------------------------------------------
+    // one box-pair record, two slab tests: scene-node scan (trace.cu:51-68, 166-193) or BVH
+    // interior node (objects.cu:198-218, 244-264)
+    auto op_box = [&]() -> uint32_t {
+        const uint32_t rec_idx = L.trav ? L.cur : L.node;
+        const float4* rp = reinterpret_cast<const float4*>(pairs + rec_idx);
+        const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        const float a_min[3] = {q0.x, q0.y, q0.z}, a_max[3] = {q0.w, q1.x, q1.y};
+        const float b_min[3] = {q1.z, q1.w, q2.x}, b_max[3] = {q2.y, q2.z, q2.w};
+        const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
+        float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
+        float dA, dB;
+        const bool hitA = slab(a_min, a_max, L.qpos, L.qinv, L.limit, dA);
+        const bool hitB = slab(b_min, b_max, L.qpos, L.qinv, L.limit, dB);
+        if (hitA) tA = dA;
+        if (hitB) tB = dB;
+        if (L.trav) {
+            TALLY(bvh_interior);
+            if (!(hitA || hitB)) return resolve(false, 0, 0);
+            const bool a_near = tA <= tB;
+            stack_ref[L.sp * CRT_BLOCK + tid] = a_near ? ref_b : ref_a;
+            stack_t[L.sp * CRT_BLOCK + tid] = fmaxf(tA, tB);
+            L.sp++;
+            return resolve(true, a_near ? ref_a : ref_b, fminf(tA, tB));
+        }
+        // scan: node `node` is half A, node + 1 is half B
+        uint32_t enter_node = kRefNone, enter_kind = 0;
+        const uint32_t kind_a = node_ref_kind(ref_a);
+        uint32_t nxt = L.node + 1;
+        if (kind_a != CRT_OBJ_NONE) {
+            TALLY(node_box_tests);
+            if (L.shadow) {
+                if (hitA) { enter_node = L.node; enter_kind = kind_a; }
+                else nxt = node_ref_after(ref_a);              // skip the subtree (trace.cu:171-185)
+            } else if (hitA && tA < L.hz) { enter_node = L.node; enter_kind = kind_a; }
+        }
+        if (enter_node == kRefNone && nxt == L.node + 1 && nxt < node_count) {
+            const uint32_t kind_b = node_ref_kind(ref_b);
+            nxt = L.node + 2;
+            if (kind_b != CRT_OBJ_NONE) {
+                TALLY(node_box_tests);
+                if (L.shadow) {
+                    if (hitB) { enter_node = L.node + 1; enter_kind = kind_b; }
+                    else nxt = node_ref_after(ref_b);
+                } else if (hitB && tB < L.hz) { enter_node = L.node + 1; enter_kind = kind_b; }
+            }
+        }
+        if (enter_node != kRefNone) { L.pend = enter_node | (enter_kind << 30); return S_ENTER; }
+        L.node = nxt;
+        return after_scan();
+    };
+
+    // one triangle of the pending leaf (IntersectTriangle / IntersectShadowTriangle, objects.cu:270-366)
+    auto op_leaf = [&]() -> uint32_t {
+        const uint32_t slot = leaf_start(L.pend), left = leaf_count(L.pend) - 1;
+        L.pend = make_leaf_ref(slot + 1, left);
+        TALLY(tri_tests);
+        const float4* tp = reinterpret_cast<const float4*>(tris + slot);
+        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        const f3 p0 = mk3(v0.x, v0.y, v0.z);
+        const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
+        const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
+        const f3 rXe2 = cross(L.qdir, edge2);
+        const float det = dot(edge1, rXe2);
+        bool ok = !(det > -CRT_TRI_EPS && det < CRT_TRI_EPS);
+        const float idet = 1 / det;
+        const f3 offset = L.qpos - p0;
+        const float b1 = idet * dot(offset, rXe2);
+        ok = ok && !(b1 <= CRT_TRI_EPS || b1 >= 1 + CRT_TRI_EPS);
+        const f3 oXe1 = cross(offset, edge1);
+        const float b2 = idet * dot(L.qdir, oXe1);
+        ok = ok && !(b2 <= -CRT_TRI_EPS || (b1 + b2) >= 1 + CRT_TRI_EPS);
+        const float t = idet * dot(edge2, oXe1);
+        const float far_limit = (L.shadow ? L.limit : L.hz) + CRT_TRI_EPS;
+        ok = ok && !(t <= CRT_TRI_EPS || t >= far_limit);
+        const float ndot = dot(cross(edge1, edge2), L.qdir);
+        ok = ok && ((ndot < CRT_TRI_EPS) || (ndot > -CRT_TRI_EPS));
+        if (ok) {
+            if (L.shadow) return finish_shadow(true);
+            TALLY(tri_hits);
+            L.hz = t;
+            L.mesh_hit = true;
+            L.h_kind = H_MESH; L.h_node = L.entered; L.h_a = b1; L.h_b = b2; L.h_c = slot; L.h_front = ndot < 0;
+        }
+        if (left) return S_LEAF;
+        return resolve(false, 0, 0);
+    };
+
+    // enter a scene node: Node::ToLocal, then the sphere / plane test in place or the start of a
+    // BVH walk (trace.cu:61-66, 188-191; objects.cu:7-159)
+    auto op_enter = [&]() -> uint32_t {
+        const uint32_t enter_node = L.pend & 0x3fffffffu, kind = L.pend >> 30;
+        TALLY(node_enters);
+        const NodeXf* __restrict__ xf = S.xf + enter_node;
+        L.qpos = xform_point(xf->itm, L.qpos);
+        L.qdir = xform_dir(xf->itm, L.qdir);
+        if (kind == CRT_OBJ_MESH) {
+            L.qinv = recip3(L.qdir);
+            L.trav = true; L.entered = enter_node; L.sp = 0; L.mesh_hit = false;
+            return resolve(true, xf->root_ref, 0.0f);
+        }
+        const f3 pos = L.qpos, dir = L.qdir;
+        bool got = false, front = true;
+        float t = 0;
+        if (kind == CRT_OBJ_SPHERE) {
+            TALLY(sphere_tests);
+            if (!(dot(dir, pos) >= 0)) {
+                const float a = dot(dir, dir);
+                const float b = dot(dir, pos) * 2;
+                const float c = dot(pos, pos) - 1;
+                const float det = b * b - 4 * a * c;
+                if (!(det < 0)) {
+                    const float sq = sqrtf(det);
+                    const float tf = (-b - sq) / (2 * a);
+                    const float tb = (-b + sq) / (2 * a);
+                    if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
+                    else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
+                    else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
                 }
             }
-
-            // Material::GenerateSample (renderer/shading.cu:11-113)
-            f3 kA = mk3(1, 1, 1);
-            if (!hit.front) {
-                const f3 e = ld3(mtl.absorption) * -hit.z;
-                kA = mk3(crtm::det_expf(e.x), crtm::det_expf(e.y), crtm::det_expf(e.z));
+        } else {
+            TALLY(plane_tests);
+            if (!(dir.z == 0)) {
+                t = -pos.z / dir.z;
+                const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
+                if (in_range && ((dir.z < 0) || (dir.z > 0))) {
+                    const f3 p = pos + t * dir;
+                    if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
+                }
             }
-            const float p = rng_float(rng);
-            f3 ndir = mk3(0, 0, 0), n_mult = mk3(0, 0, 0);
-            float n_prob = 0;
-            bool alive = true;
-            if (p < pD) {
-                const float x = rng_float(rng);
-                const float phi = rng_float(rng) * 2 * F_PI;
+        }
+        if (got) {
+            if (L.shadow) return finish_shadow(true);
+            const f3 p = pos + t * dir;
+            L.hz = t;
+            L.hpos = xform_point(xf->tm, p);
+            L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
+            L.h_node = enter_node; L.h_front = front;
+            L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
+        }
+        L.qpos = xform_point(xf->tm, L.qpos);
+        L.qdir = xform_dir(xf->tm, L.qdir);
+        L.qinv = recip3(L.qdir);
+        L.node = enter_node + 1;
+        return after_scan();
+    };
+
+    // leave a mesh: world position of its hit, Node::FromLocal for the ray (trace.cu:64-66, 191)
+    auto op_exit = [&]() -> uint32_t {
+        const NodeXf* __restrict__ xf = S.xf + L.entered;
+        if (L.mesh_hit) L.hpos = xform_point(xf->tm, L.qpos + L.hz * L.qdir);
+        L.qpos = xform_point(xf->tm, L.qpos);
+        L.qdir = xform_dir(xf->tm, L.qdir);
+        L.qinv = recip3(L.qdir);
+        L.trav = false;
+        L.node = L.entered + 1;
+        return after_scan();
+    };
+
+    // a new path: camera ray (trace.cu:26-38)
+    auto op_camera = [&]() -> uint32_t {
+        const uint32_t pY = L.pI / S.width, pX = L.pI - pY * S.width;
+        camera_ray(S, pX, pY, L.rng, L.qpos, L.qdir);
+        L.contrib = mk3(1, 1, 1) * inv_samples;
+        L.segments = 0;
+        TALLY(paths);
+        return start_closest();
+    };
+
+    // the closest-hit query has ended: lights, then TracePath's body (trace.cu:72-78, 91-157)
+    auto op_shade = [&]() -> uint32_t {
+        // lights are intersected last, with the ray as the node loop left it
+        int hit_light = -1;
+        f3 light_n = mk3(0, 0, 0);
+        for (uint32_t i = 0; i < S.light_count; i++) {
+            const DevLight Li = S.lights[i];
+            if (Li.kind != CRT_LIGHT_POINT) continue;
+            // PointLight::Intersect (scene/lights.cu:36-89)
+            const f3 lp = ld3(Li.pos);
+            const f3 o = L.qpos - lp;
+            const float a = dot(L.qdir, L.qdir);
+            const float b = dot(2 * L.qdir, o);
+            const float c = dot(o, o) - Li.size * Li.size;
+            const float det = b * b - 4 * a * c;
+            if (det < 0) continue;
+            const float sq = sqrtf(det);
+            const float tf = (-b - sq) / (2 * a);
+            const float tb = (-b + sq) / (2 * a);
+            if (tf >= 0) {
+                if (tf >= L.hz) continue;
+                L.hz = tf;
+                light_n = normalized(o);
+                L.hpos = L.qpos + tf * L.qdir;
+                hit_light = (int)i;
+                continue;
+            }
+            if (tb < 0) continue;
+            if (tb >= L.hz) continue;
+            L.hz = tb;
+            light_n = normalized(L.hpos);          // the previous hit position, as the reference reads it (lights.cu:78)
+            L.hpos = L.qpos + tb * L.qdir;
+            hit_light = (int)i;
+        }
+        const bool any = hit_light >= 0 || L.h_kind != H_NONE;
+
+        if (kPrimary) {
+            int32_t id = -1, face = -1;
+            if (hit_light >= 0) id = -2 - hit_light;
+            else if (any) { id = (int32_t)L.h_node; if (L.h_kind == H_MESH) face = (int32_t)tris[L.h_c].face; }
+            out_node[L.pI] = id; out_face[L.pI] = face; out_t[L.pI] = L.hz;
+            return end_path();
+        }
+
+        if (!any) {
+            const f3 env = tex_env<kCount>(S, L.qdir, tally);
+            L.target += L.contrib * env;
+            L.normal += L.contrib * normalized(L.qdir);
+            L.albedo += L.contrib * env;
+            return end_path();
+        }
+        if (hit_light >= 0) {
+            const f3 rad = ld3(S.lights[hit_light].radiance);
+            L.target += L.contrib * rad;
+            L.normal += L.contrib * light_n;
+            L.albedo += L.contrib * rad;
+            return end_path();
+        }
+
+        // normal and texture coordinates of the hit (objects.cu:44-50, 126-131, 308-320) and
+        // Node::FromLocal for the normal (scene/scene.cuh:185-189)
+        const NodeXf* __restrict__ xf = S.xf + L.h_node;
+        f3 n, uvw;
+        if (L.h_kind == H_MESH) {
+            const float4* tp = reinterpret_cast<const float4*>(tris + L.h_c);
+            const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            const f3 p0 = mk3(v0.x, v0.y, v0.z);
+            const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
+            const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
+            const uint32_t face = __float_as_uint(v0.w);
+            const float b1 = L.h_a, b2 = L.h_b;
+            const float b0 = 1 - b2 - b1;
+            const DevMesh M = S.meshes[xf->mesh_id];
+            if (!M.has_normals) n = normalized(cross(edge1, edge2));
+            else {
+                const uint32_t i0 = M.fn[3 * face], i1 = M.fn[3 * face + 1], i2 = M.fn[3 * face + 2];
+                n = ld3(M.vn + 3 * i0) * b0 + ld3(M.vn + 3 * i1) * b1 + ld3(M.vn + 3 * i2) * b2;
+            }
+            if (!M.has_tex) uvw = mk3(0, 0, 0);
+            else {
+                const uint32_t i0 = M.ft[3 * face], i1 = M.ft[3 * face + 1], i2 = M.ft[3 * face + 2];
+                uvw = ld3(M.vt + 3 * i0) * b0 + ld3(M.vt + 3 * i1) * b1 + ld3(M.vt + 3 * i2) * b2;
+            }
+        } else {
+            const f3 p = mk3(L.h_a, L.h_b, __uint_as_float(L.h_c));
+            if (L.h_kind == H_SPHERE) {
+                n = p;
+                uvw = mk3(0.5f * 0.318309f * crtm::det_atan2f(p.y, p.x) + 0.5f,
+                          0.318309f * crtm::det_asinf(fminf(fmaxf(p.z, -1.0f), 1.0f)) + 0.5f, 0);
+            } else {
+                n = mk3(0, 0, 1);
+                uvw = 0.5f * (p + mk3(1, 1, 0));
+            }
+        }
+        n = xform_normal(xf->itm, n);
+        const f3 hpos = L.hpos;
+        const f3 v = L.v;
+
+        const float light_pick = rng_float(L.rng);
+        const DevMaterial mtl = S.materials[xf->material_id];
+        const f3 kD = tex_eval<kCount>(S, mtl.diffuse, uvw, tally);
+        const f3 kS = tex_eval<kCount>(S, mtl.specular, uvw, tally);
+        const f3 kT = tex_eval<kCount>(S, mtl.refraction, uvw, tally);
+        const f3 kE = tex_eval<kCount>(S, mtl.emission, uvw, tally);
+        L.normal += L.contrib * n;
+        L.albedo += L.contrib * kD + kE;
+        L.target += L.contrib * kE;
+
+        // lobe probabilities (renderer/shading.cu:17-29 and 122-134)
+        const float third = 1.0f / 3.0f;
+        float pD = (kD.x + kD.y + kD.z) * third;
+        float pS = (kS.x + kS.y + kS.z) * third;
+        float pT = (kT.x + kT.y + kT.z) * third;
+        if (pD + pS + pT > CRT_MAX_SURVIVAL) {
+            const float norm = CRT_MAX_SURVIVAL / (pD + pS + pT);
+            pD *= norm; pS *= norm; pT *= norm;
+        }
+        const float g = mtl.glossiness;
+
+        // next-event estimation toward one light (trace.cu:112-143).  Ambient and directional
+        // lights produce no sample and zero weight, so nothing is traced for them; with no light
+        // at all (where the reference reads a null light) no sample is taken either.
+        bool want_shadow = false;
+        f3 spos = mk3(0, 0, 0), sdir = mk3(0, 0, 1);
+        float sdist = 0;
+        L.nee_valid = false;
+        if (S.light_count > 0) {
+            const int light_id = crtm::f2i_sat(light_pick * (float)S.light_count);
+            const DevLight Ls = S.lights[light_id];
+            if (Ls.kind == CRT_LIGHT_POINT) {
+                // PointLight::GenerateSample (scene/lights.cu:10-34)
+                const f3 lp = ld3(Ls.pos);
+                const f3 Ldir = normalized(hpos - lp);
+                const float x = rng_float(L.rng);
+                const float phi = rng_float(L.rng) * 2 * F_PI;
                 const float cos_theta = 1 - x;
                 const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-                f3 u, w;
-                orthonormals(hit.n, u, w);
-                ndir = hit.n * cos_theta + u * sin_theta * crtm::det_cosf(phi) + w * sin_theta * crtm::det_sinf(phi);
-                n_prob = pD * OVERPI;
-                n_mult = kA * kD * OVERPI * dot(hit.n, ndir);
-            } else {
-                const f3 gln = glossy_normal(hit.n, g, rng);
-                if (p < pD + pS) {
-                    ndir = reflect(v, gln);
-                    const float pw = crtm::det_powf(dot(gln, hit.n), g);
-                    n_prob = pS * (g + 1) * 0.125f * OVERPI * pw;
-                    n_mult = kA * kS * (g + 2) * 0.125f * OVERPI * pw;
-                } else if (p < pD + pS + pT) {
-                    const float eta_i = hit.front ? 1 : mtl.ior;
-                    const float eta_o = hit.front ? mtl.ior : 1;
-                    const f3 h = hit.front ? gln : -gln;
-                    bool tir = false;
-                    ndir = transmit(v, h, eta_i, eta_o, tir);
-                    const float f_0 = crtm::det_powf((eta_i - eta_o) / (eta_i + eta_o), 2);
-                    const float cos_theta = dot(v, h);
-                    float f_theta = f_0 + (1 - f_0) * crtm::det_powf(1 - cos_theta, 5);
-                    f_theta = fminf(fmaxf(f_theta, 0.0f), 1.0f);
-                    if (!tir) {
-                        if (rng_float(rng) >= f_theta) {
-                            n_prob = pT * (1 - f_theta);
-                            n_mult = kA * kT * (1 - f_theta);
-                        } else {
-                            ndir = reflect(v, h);
-                            n_prob = pT * f_theta;
-                            n_mult = kA * kT * f_theta;
-                        }
-                    } else {
-                        n_prob = pT;
-                        n_mult = kA * kT;
-                    }
-                } else {
-                    alive = false;
+                f3 a, b;
+                orthonormals(Ldir, a, b);
+                const f3 ln = Ldir * cos_theta + a * sin_theta * crtm::det_cosf(phi) + b * sin_theta * crtm::det_sinf(phi);
+                const f3 tgt = lp + ln * Ls.size;
+                const f3 ldir = normalized(tgt - hpos);
+                const float d2 = lengthsq(tgt - hpos);
+                const float cos_theta_l = dot(ldir, -normalized(tgt - lp));
+                const float l_prob = d2 / (2 * F_PI * Ls.size * Ls.size * cos_theta_l);
+                const f3 l_mult = ld3(Ls.radiance);
+                sdist = sqrtf(d2);
+                // Material::GetSampleInfo (renderer/shading.cu:116-150)
+                float b_prob = 0.0f;
+                f3 b_mult = mk3(0, 0, 0);
+                const float ndl = dot(n, ldir);
+                if (ndl >= 0) {
+                    b_prob += pD * (ndl > 0 ? OVERPI : 0);
+                    b_mult += kD * OVERPI * ndl;
+                    const f3 rn = normalized(v + ldir);
+                    const float ndh = dot(n, rn);
+                    b_prob += pS * (g + 1) * 0.5f * OVERPI * crtm::det_powf(ndh, g + 1);
+                    b_mult += kS * (g + 2) * 0.125f * OVERPI * crtm::det_powf(ndh, g);
                 }
-            }
-            if (!alive) path_done = true;
-            else {
-                rpos = hit.pos;
-                rdir = ndir;
-                if (n_prob <= CRT_F_EPS) path_done = true;
-                else {
-                    contrib *= n_mult * (1.0f / n_prob);
-                    if (++segments >= CRT_MAX_SEGMENTS) path_done = true;
+                const float denom = l_prob * l_prob + b_prob * b_prob;
+                if (denom > CRT_F_EPS && l_prob > CRT_F_EPS) {
+                    const float pop = l_prob / denom;
+                    L.nee = L.contrib * l_mult * b_mult * pop;
+                    L.nee_valid = true;
                 }
+                // TraceShadowRay prologue (trace.cu:160-162)
+                spos = hpos; sdir = ldir;
+                spos += sdir * CRT_BIAS + n * CRT_BIAS;
+                want_shadow = true;
             }
         }
 
-        if (path_done) {
-            new_path = true;
-            if (++sample >= samples) {
-                float* r = S.results + 3ull * pI;
-                float* nn = S.normals + 3ull * pI;
-                float* al = S.albedos + 3ull * pI;
-                r[0] = target.x; r[1] = target.y; r[2] = target.z;
-                nn[0] = normal.x; nn[1] = normal.y; nn[2] = normal.z;
-                al[0] = albedo.x; al[1] = albedo.y; al[2] = albedo.z;
-                have_pixel = false;
+        // Material::GenerateSample (renderer/shading.cu:11-113)
+        f3 kA = mk3(1, 1, 1);
+        if (!L.h_front) {
+            const f3 e = ld3(mtl.absorption) * -L.hz;
+            kA = mk3(crtm::det_expf(e.x), crtm::det_expf(e.y), crtm::det_expf(e.z));
+        }
+        const float p = rng_float(L.rng);
+        f3 ndir = mk3(0, 0, 0), n_mult = mk3(0, 0, 0);
+        float n_prob = 0;
+        bool alive = true;
+        if (p < pD) {
+            const float x = rng_float(L.rng);
+            const float phi = rng_float(L.rng) * 2 * F_PI;
+            const float cos_theta = 1 - x;
+            const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+            f3 u, w;
+            orthonormals(n, u, w);
+            ndir = n * cos_theta + u * sin_theta * crtm::det_cosf(phi) + w * sin_theta * crtm::det_sinf(phi);
+            n_prob = pD * OVERPI;
+            n_mult = kA * kD * OVERPI * dot(n, ndir);
+        } else {
+            const f3 gln = glossy_normal(n, g, L.rng);
+            if (p < pD + pS) {
+                ndir = reflect(v, gln);
+                const float pw = crtm::det_powf(dot(gln, n), g);
+                n_prob = pS * (g + 1) * 0.125f * OVERPI * pw;
+                n_mult = kA * kS * (g + 2) * 0.125f * OVERPI * pw;
+            } else if (p < pD + pS + pT) {
+                const float eta_i = L.h_front ? 1 : mtl.ior;
+                const float eta_o = L.h_front ? mtl.ior : 1;
+                const f3 h = L.h_front ? gln : -gln;
+                bool tir = false;
+                ndir = transmit(v, h, eta_i, eta_o, tir);
+                const float f_0 = crtm::det_powf((eta_i - eta_o) / (eta_i + eta_o), 2);
+                const float cos_theta = dot(v, h);
+                float f_theta = f_0 + (1 - f_0) * crtm::det_powf(1 - cos_theta, 5);
+                f_theta = fminf(fmaxf(f_theta, 0.0f), 1.0f);
+                if (!tir) {
+                    if (rng_float(L.rng) >= f_theta) {
+                        n_prob = pT * (1 - f_theta);
+                        n_mult = kA * kT * (1 - f_theta);
+                    } else {
+                        ndir = reflect(v, h);
+                        n_prob = pT * f_theta;
+                        n_mult = kA * kT * f_theta;
+                    }
+                } else {
+                    n_prob = pT;
+                    n_mult = kA * kT;
+                }
+            } else {
+                alive = false;
+            }
+        }
+        // the path continues unless the sample died, its probability vanished or the safety bound hit
+        L.path_alive = false;
+        if (alive) {
+            L.ndir = ndir;
+            if (!(n_prob <= CRT_F_EPS)) {
+                L.contrib *= n_mult * (1.0f / n_prob);
+                L.path_alive = ++L.segments < CRT_MAX_SEGMENTS;
+            }
+        }
+        if (want_shadow) {
+            tally.shadow_rays++;
+            L.qpos = spos; L.qdir = sdir; L.qinv = recip3(sdir);
+            L.limit = sdist;
+            L.shadow = true; L.trav = false; L.node = 0;
+            return S_BOX;
+        }
+        return continue_path();
+    };
+
+    // ---- the scheduler ---------------------------------------------------------------------
+    for (;;) {
+        uint32_t best = S_BOX;
+        if (__popcll(__ballot(state == S_BOX)) < 32) {
+            uint32_t best_n = 0;
+            best = S_DONE;
+#pragma unroll
+            for (uint32_t s = 0; s < S_DONE; s++) {
+                const uint32_t n = (uint32_t)__popcll(__ballot(state == s));
+                if (n > best_n) { best_n = n; best = s; }
+            }
+            if (best == S_DONE) break;
+        }
+        switch (best) {
+            case S_BOX: if (state == S_BOX) state = op_box(); break;
+            case S_LEAF: if (state == S_LEAF) state = op_leaf(); break;
+            case S_ENTER: if (state == S_ENTER) state = op_enter(); break;
+            case S_EXIT: if (state == S_EXIT) state = op_exit(); break;
+            case S_SHADE: if (state == S_SHADE) state = op_shade(); break;
+            case S_CAMERA: if (state == S_CAMERA) state = op_camera(); break;
+            default: {
+                // S_FETCH: idle lanes take consecutive items from the pixel queue with one atomic per wave
+                const bool need = state == S_FETCH;
+                const unsigned long long mask = __ballot(need);
+                if (queue_empty) { if (need) state = S_DONE; break; }
+                uint32_t base = 0;
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                if (need && lane_rank(mask) == 0) base = atomicAdd(queue, cnt);
+                base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+                if (base + cnt >= P.total_items) queue_empty = true;       // uniform: the queue has run dry
+                if (need) {
+                    const uint32_t item = base + lane_rank(mask);
+                    uint32_t pX, pY;
+                    if (item >= P.total_items) state = S_DONE;
+                    else if (item_to_pixel(S, P, item, pX, pY)) {
+                        L.pI = pY * S.width + pX;
+                        rng_init(L.rng, L.pI, jump);
+                        if (!kPrimary) {
+                            L.target = ld3(S.results + 3ull * L.pI);
+                            L.normal = ld3(S.normals + 3ull * L.pI);
+                            L.albedo = ld3(S.albedos + 3ull * L.pI);
+                        }
+                        L.sample = 0;
+                        state = S_CAMERA;
+                    }                                   // else: item outside the image, fetch again
+                }
+                break;
             }
         }
     }
@@ -817,7 +822,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void render_kernel(DevScene S, DevPartit
         c_th = wave_sum(tally.tri_hits); c_sp = wave_sum(tally.sphere_tests); c_pl = wave_sum(tally.plane_tests);
         c_tx = wave_sum(tally.texel_quads);
     }
-    if ((threadIdx.x & 63u) == 0) {
+    if (!kPrimary && (threadIdx.x & 63u) == 0) {
         atomicAdd(&stats->closest_rays, c_closest);
         atomicAdd(&stats->shadow_rays, c_shadow);
         if (kCount) {
@@ -827,33 +832,6 @@ __global__ __launch_bounds__(CRT_BLOCK) void render_kernel(DevScene S, DevPartit
             atomicAdd(&stats->texel_quads, c_tx);
         }
     }
-}
-
-// ------------------------------------------------------------------ parity hook: first camera ray per pixel
-__global__ __launch_bounds__(CRT_BLOCK) void primary_kernel(DevScene S, DevPartition P, const uint32_t* __restrict__ jump,
-                                                            int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
-                                                            float* __restrict__ out_t) {
-    extern __shared__ uint32_t lds[];
-    uint32_t* stack_ref = lds;
-    float* stack_t = reinterpret_cast<float*>(lds + S.stack_entries * CRT_BLOCK);
-    const uint32_t item = blockIdx.x * CRT_BLOCK + threadIdx.x;
-    uint32_t pX, pY;
-    if (item >= P.total_items || !item_to_pixel(S, P, item, pX, pY)) return;
-    const uint32_t pI = pY * S.width + pX;
-    Rng rng;
-    rng_init(rng, pI, jump);
-    f3 rpos, rdir;
-    camera_ray(S, pX, pY, rng, rpos, rdir);
-    HitRec hit;
-    hit_init(hit);
-    Tally tally = {};
-    rpos += rdir * CRT_BIAS;
-    const bool any = trace_scene<false, false>(S, rpos, rdir, CRT_BIGFLOAT, hit, stack_ref, stack_t, tally);
-    int32_t id = -1;
-    if (any) id = hit.light >= 0 ? -2 - hit.light : hit.node;
-    out_node[pI] = id;
-    out_face[pI] = (any && hit.light < 0) ? hit.face : -1;
-    out_t[pI] = hit.z;
 }
 
 // ------------------------------------------------------------------ ConvertColors (math/color.cu:7-23)

@@ -16,7 +16,7 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
         n[(k, r["Counter_Name"])] += 1
     out.append(f"== {os.path.relpath(f, d)} (sum over dispatches; dispatches per counter in brackets)")
     for k in acc:
-        if "render_kernel" not in k and "convert" not in k: continue
+        if "render_kernel" not in k and "trace_kernel" not in k and "convert" not in k: continue
         for c, v in sorted(acc[k].items()):
             out.append(f"{k:60s} {c:32s} {v:.6g} [{n[(k,c)]}]")
 print("\n".join(out))
