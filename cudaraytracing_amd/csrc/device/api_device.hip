@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -389,6 +390,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
     S.stack_entries = max_depth + 2;
+    S.sched_box_min = 32;
+    if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);
     if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
         (rc = upload(ctx, meshes, &S.meshes)) || (rc = upload(ctx, materials, &S.materials)) ||
         (rc = upload(ctx, textures, &S.textures)) || (rc = upload(ctx, texels, &S.texels)) || (rc = upload(ctx, lights, &S.lights)))
@@ -603,6 +606,7 @@ int crt_get_stats(crt_ctx* ctx, crt_stats* out) {
     out->node_box_tests = s.node_box_tests; out->node_enters = s.node_enters; out->bvh_interior = s.bvh_interior;
     out->bvh_leaves = s.bvh_leaves; out->tri_tests = s.tri_tests; out->tri_hits = s.tri_hits;
     out->sphere_tests = s.sphere_tests; out->plane_tests = s.plane_tests; out->texel_quads = s.texel_quads;
+    for (int k = 0; k < 8; k++) { out->sched_turns[k] = s.sched_turns[k]; out->sched_lanes[k] = s.sched_lanes[k]; }
     return CRT_OK;
 }
 

@@ -105,6 +105,7 @@ struct DevScene {
     uint32_t node_count, light_count;
     int32_t env_texture;
     uint32_t stack_entries;          // LDS stack slots per lane
+    uint32_t sched_box_min;          // box steps keep running while this many lanes of a wave want one
     const BoxPair* pairs;
     const TriRec* tris;
     const NodeXf* xf;
@@ -133,6 +134,7 @@ struct DevStats {
     unsigned long long closest_rays, shadow_rays, paths;
     unsigned long long node_box_tests, node_enters, bvh_interior, bvh_leaves;
     unsigned long long tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
+    unsigned long long sched_turns[8], sched_lanes[8];
 };
 
 }  // namespace crt

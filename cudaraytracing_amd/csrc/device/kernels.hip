@@ -91,6 +91,7 @@ DEV void rng_init(Rng& s, uint32_t seed_lo, const uint32_t* __restrict__ jump) {
 struct Tally {
     uint32_t closest_rays, shadow_rays, paths;
     uint32_t node_box_tests, node_enters, bvh_interior, bvh_leaves, tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
+    uint32_t turns[8], lanes[8];
 };
 #define TALLY(field) do { if (kCount) tally.field++; } while (0)
 
@@ -266,7 +267,7 @@ struct Lane {
 
 // ------------------------------------------------------------------ the scheduled path tracer
 template <bool kCount, bool kPrimary>
-__global__ __launch_bounds__(CRT_BLOCK) void trace_kernel(DevScene S, DevPartition P, int samples,
+__global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPartition P, int samples,
                                                           const uint32_t* __restrict__ jump,
                                                           uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
                                                           int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
@@ -764,8 +765,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void trace_kernel(DevScene S, DevPartiti
 
     // ---- the scheduler ---------------------------------------------------------------------
     for (;;) {
+        // Which operation runs this turn: box steps while at least sched_box_min lanes want one,
+        // otherwise whatever the largest number of lanes is waiting for.
         uint32_t best = S_BOX;
-        if (__popcll(__ballot(state == S_BOX)) < 32) {
+        if ((uint32_t)__popcll(__ballot(state == S_BOX)) < S.sched_box_min) {
             uint32_t best_n = 0;
             best = S_DONE;
 #pragma unroll
@@ -776,15 +779,16 @@ __global__ __launch_bounds__(CRT_BLOCK) void trace_kernel(DevScene S, DevPartiti
             if (best == S_DONE) break;
         }
         switch (best) {
-            case S_BOX: if (state == S_BOX) state = op_box(); break;
-            case S_LEAF: if (state == S_LEAF) state = op_leaf(); break;
-            case S_ENTER: if (state == S_ENTER) state = op_enter(); break;
-            case S_EXIT: if (state == S_EXIT) state = op_exit(); break;
-            case S_SHADE: if (state == S_SHADE) state = op_shade(); break;
-            case S_CAMERA: if (state == S_CAMERA) state = op_camera(); break;
+            case S_BOX: if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; } if (state == S_BOX) state = op_box(); break;
+            case S_LEAF: if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); break;
+            case S_ENTER: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_ENTER; } if (state == S_ENTER) state = op_enter(); break;
+            case S_EXIT: if (kCount) { tally.turns[3]++; tally.lanes[3] += state == S_EXIT; } if (state == S_EXIT) state = op_exit(); break;
+            case S_SHADE: if (kCount) { tally.turns[4]++; tally.lanes[4] += state == S_SHADE; } if (state == S_SHADE) state = op_shade(); break;
+            case S_CAMERA: if (kCount) { tally.turns[5]++; tally.lanes[5] += state == S_CAMERA; } if (state == S_CAMERA) state = op_camera(); break;
             default: {
                 // S_FETCH: idle lanes take consecutive items from the pixel queue with one atomic per wave
                 const bool need = state == S_FETCH;
+                if (kCount) { tally.turns[6]++; tally.lanes[6] += need; }
                 const unsigned long long mask = __ballot(need);
                 if (queue_empty) { if (need) state = S_DONE; break; }
                 uint32_t base = 0;
@@ -830,6 +834,13 @@ __global__ __launch_bounds__(CRT_BLOCK) void trace_kernel(DevScene S, DevPartiti
             atomicAdd(&stats->bvh_interior, c_bi); atomicAdd(&stats->bvh_leaves, c_bl); atomicAdd(&stats->tri_tests, c_tt);
             atomicAdd(&stats->tri_hits, c_th); atomicAdd(&stats->sphere_tests, c_sp); atomicAdd(&stats->plane_tests, c_pl);
             atomicAdd(&stats->texel_quads, c_tx);
+        }
+    }
+    if (kCount && !kPrimary) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const unsigned long long t = wave_sum(tally.turns[k]), l = wave_sum(tally.lanes[k]);
+            if ((threadIdx.x & 63u) == 0) { atomicAdd(&stats->sched_turns[k], t / 64); atomicAdd(&stats->sched_lanes[k], l); }
         }
     }
 }

@@ -72,6 +72,11 @@ class Context:
         self._check(capi.lib().crt_get_stats(self._h, C.byref(s)))
         return s.as_dict()
 
+    def schedule_stats(self):
+        s = capi.Stats()
+        self._check(capi.lib().crt_get_stats(self._h, C.byref(s)))
+        return s.schedule()
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._check(capi.lib().crt_last_kernel_ms(self._h, C.byref(ms)))
