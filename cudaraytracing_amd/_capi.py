@@ -69,15 +69,15 @@ class BvhArrays(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("closest_rays", "shadow_rays", "paths", "node_box_tests", "node_enters",
                                            "bvh_interior", "bvh_leaves", "tri_tests", "tri_hits", "sphere_tests",
-                                           "plane_tests", "texel_quads")] + [("sched_turns", C.c_uint64 * 8), ("sched_lanes", C.c_uint64 * 8)]
+                                           "plane_tests", "texel_quads")] + [("sched_turns", C.c_uint64 * 8), ("sched_lanes", C.c_uint64 * 8), ("sched_cycles", C.c_uint64 * 8), ("path_cycles", C.c_uint64 * 8)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_[:12]}
 
     def schedule(self):
-        """Per operation (box, triangle, enter, exit, shade, camera, fetch): wave turns and lanes served."""
-        names = ("box", "triangle", "enter", "exit", "shade", "camera", "fetch")
-        return {n: (int(self.sched_turns[i]), int(self.sched_lanes[i])) for i, n in enumerate(names)}
+        """Per operation (box, triangle, transform, path, fetch): wave turns and lanes served."""
+        names = ("box", "triangle", "transform", "path", "fetch")
+        return {n: (int(self.sched_turns[i]), int(self.sched_lanes[i]), int(self.sched_cycles[i])) for i, n in enumerate(names)}
 
 
 # every symbol include/crt_amd.h declares: name -> (restype, argtypes)

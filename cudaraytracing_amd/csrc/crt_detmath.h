@@ -123,6 +123,15 @@ CRT_HD float det_powf(float x, float y) {
         if (y > 0.0f) return yodd ? -make_inf() : make_inf();
         return yodd ? -0.0f : 0.0f;
     }
+    if (yint && fabsf(y) <= 2048.0f) {
+        // integer exponent: binary powering in double (at most 22 roundings, ~2e-15 relative)
+        double b = (double)x, r = 1.0;
+        for (unsigned n = (unsigned)fabsf(y); n; n >>= 1) {
+            if (n & 1u) r = r * b;
+            b = b * b;
+        }
+        return (float)(y < 0.0f ? 1.0 / r : r);
+    }
     double sign = 1.0;
     double ax = (double)x;
     if (x < 0.0f) {
@@ -188,6 +197,22 @@ CRT_HD double cos_core(double x) {
         case 2: return -cos_poly(r);
         default: return sin_poly(r);
     }
+}
+
+CRT_HD void det_sincosf(float x, float& s, float& c) {
+    if (is_nan(x) || is_inf(x)) { s = make_nan(); c = make_nan(); return; }
+    double r;
+    const int n = rem_pio2((double)x, r);
+    const double sp = sin_poly(r), cp = cos_poly(r);
+    double sv, cv;
+    switch (n) {
+        case 0: sv = sp; cv = cp; break;
+        case 1: sv = cp; cv = -sp; break;
+        case 2: sv = -sp; cv = -cp; break;
+        default: sv = -cp; cv = sp; break;
+    }
+    s = x == 0.0f ? x : (float)sv;
+    c = (float)cv;
 }
 
 CRT_HD float det_sinf(float x) {

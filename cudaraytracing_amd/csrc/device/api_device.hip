@@ -25,6 +25,7 @@ struct crt_ctx {
     std::vector<void*> allocs;                 // everything owned by the current scene
     uint8_t* rgb8 = nullptr;
     uint32_t* queue = nullptr;
+    uint32_t* cold = nullptr;                  // per-thread path state of the trace kernel
     DevStats* stats = nullptr;
     std::map<int, uint32_t*> jumps;            // pass -> 160 x 5 jump matrix on the device
     static constexpr int kRing = 256;
@@ -390,8 +391,10 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
     S.stack_entries = max_depth + 2;
-    S.sched_box_min = 32;
+    S.sched_box_min = 16; S.sched_special_min = 6; S.sched_heavy_min = 1;      // measured optimum on the benchmark frame
     if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);
+    if (const char* e = getenv("CRT_SCHED_SPECIAL_MIN")) S.sched_special_min = (uint32_t)atoi(e);
+    if (const char* e = getenv("CRT_SCHED_HEAVY_MIN")) S.sched_heavy_min = (uint32_t)atoi(e);
     if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
         (rc = upload(ctx, meshes, &S.meshes)) || (rc = upload(ctx, materials, &S.materials)) ||
         (rc = upload(ctx, textures, &S.textures)) || (rc = upload(ctx, texels, &S.texels)) || (rc = upload(ctx, lights, &S.lights)))
@@ -420,6 +423,12 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, (trace_kernel<true, false>), CRT_BLOCK, ctx->lds_bytes));
     if (ctx->blocks_per_cu < 1) ctx->blocks_per_cu = 1;
     if (ctx->blocks_per_cu_counted < 1) ctx->blocks_per_cu_counted = 1;
+    {
+        const int per_cu = ctx->blocks_per_cu > ctx->blocks_per_cu_counted ? ctx->blocks_per_cu : ctx->blocks_per_cu_counted;
+        const size_t threads = (size_t)ctx->num_cus * per_cu * CRT_BLOCK;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->cold, threads * C_WORDS * 4));
+        ctx->allocs.push_back(ctx->cold);
+    }
 
     ctx->have_scene = true;
     set_partition(ctx, 0, 1, 16);
@@ -474,9 +483,9 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     const int slot = (int)(ctx->launches % crt_ctx::kRing);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], stream));
     if (counted)
-        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
     else
-        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], stream));
     ctx->launches++;
@@ -586,7 +595,7 @@ int crt_primary_hits(crt_ctx* ctx, int pass_id, int32_t* node, int32_t* face, fl
         const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
         if (grid > need) grid = need;
         hipLaunchKernelGGL((trace_kernel<false, true>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, nullptr,
-                           ctx->S, ctx->P, 1, jump, ctx->queue, ctx->stats, d_node, d_face, d_t);
+                           ctx->S, ctx->P, 1, jump, ctx->queue, ctx->stats, d_node, d_face, d_t, ctx->cold);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipDeviceSynchronize());
@@ -606,7 +615,7 @@ int crt_get_stats(crt_ctx* ctx, crt_stats* out) {
     out->node_box_tests = s.node_box_tests; out->node_enters = s.node_enters; out->bvh_interior = s.bvh_interior;
     out->bvh_leaves = s.bvh_leaves; out->tri_tests = s.tri_tests; out->tri_hits = s.tri_hits;
     out->sphere_tests = s.sphere_tests; out->plane_tests = s.plane_tests; out->texel_quads = s.texel_quads;
-    for (int k = 0; k < 8; k++) { out->sched_turns[k] = s.sched_turns[k]; out->sched_lanes[k] = s.sched_lanes[k]; }
+    for (int k = 0; k < 8; k++) { out->sched_turns[k] = s.sched_turns[k]; out->sched_lanes[k] = s.sched_lanes[k]; out->sched_cycles[k] = s.sched_cycles[k]; out->path_cycles[k] = s.path_cycles[k]; }
     return CRT_OK;
 }
 

@@ -105,7 +105,9 @@ struct DevScene {
     uint32_t node_count, light_count;
     int32_t env_texture;
     uint32_t stack_entries;          // LDS stack slots per lane
-    uint32_t sched_box_min;          // box steps keep running while this many lanes of a wave want one
+    uint32_t sched_box_min;          // box steps run unconditionally while this many lanes of a wave want one
+    uint32_t sched_special_min;      // a triangle / transform turn runs once this many lanes wait for it
+    uint32_t sched_heavy_min;        // a path / fetch turn outvoting the box lanes needs this many lanes
     const BoxPair* pairs;
     const TriRec* tris;
     const NodeXf* xf;
@@ -134,7 +136,8 @@ struct DevStats {
     unsigned long long closest_rays, shadow_rays, paths;
     unsigned long long node_box_tests, node_enters, bvh_interior, bvh_leaves;
     unsigned long long tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
-    unsigned long long sched_turns[8], sched_lanes[8];
+    unsigned long long sched_turns[8], sched_lanes[8], sched_cycles[8];
+    unsigned long long path_cycles[8];
 };
 
 }  // namespace crt

@@ -92,6 +92,7 @@ struct Tally {
     uint32_t closest_rays, shadow_rays, paths;
     uint32_t node_box_tests, node_enters, bvh_interior, bvh_leaves, tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
     uint32_t turns[8], lanes[8];
+    unsigned long long cycles[8];
 };
 #define TALLY(field) do { if (kCount) tally.field++; } while (0)
 
@@ -188,8 +189,8 @@ DEV f3 glossy_normal(f3 normal, float glossiness, Rng& rng) {
     f3 u, v;
     orthonormals(normal, u, v);
     const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-    const float cos_phi = crtm::det_cosf(phi);
-    const float sin_phi = crtm::det_sinf(phi);
+    float sin_phi, cos_phi;
+    crtm::det_sincosf(phi, sin_phi, cos_phi);
     return normal * cos_theta + u * sin_theta * cos_phi + v * sin_theta * sin_phi;
 }
 
@@ -200,8 +201,10 @@ DEV void camera_ray(const DevScene& S, uint32_t pX, uint32_t pY, Rng& rng, f3& p
     const float F_PI = 3.14159265358979323846f;
     const float dof_r = sqrtf(rng_float(rng));
     const float dof_theta = rng_float(rng) * 2 * F_PI;
-    const float dof_x = dof_r * crtm::det_cosf(dof_theta);
-    const float dof_y = dof_r * crtm::det_sinf(dof_theta);
+    float dof_sin, dof_cos;
+    crtm::det_sincosf(dof_theta, dof_sin, dof_cos);
+    const float dof_x = dof_r * dof_cos;
+    const float dof_y = dof_r * dof_sin;
     const f3 start = ld3(S.cam_pos) + S.dof * (dof_x * cX - dof_y * cY);
     const float aa_x = rng_float(rng) - 0.5f;
     const float aa_y = rng_float(rng) - 0.5f;
@@ -232,18 +235,21 @@ DEV unsigned long long wave_sum(unsigned long long v) {
 }
 
 // ------------------------------------------------------------------ per-lane state
-enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_ENTER = 2, S_EXIT = 3, S_SHADE = 4, S_CAMERA = 5, S_FETCH = 6, S_DONE = 7 };
+// Operation a lane needs next.
+//   BOX    slab-test one box-pair record (scene-node scan or BVH interior node)
+//   LEAF   test one triangle of the pending leaf
+//   XFORM  enter a scene node (world -> local, sphere / plane test or BVH root) or leave a mesh
+//   PATH   a query has ended or a pixel has just been fetched: shade / add the light sample /
+//          start the next query or the next path
+//   FETCH  take a pixel from the queue
+enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_XFORM = 2, S_PATH = 3, S_FETCH = 4, S_DONE = 5 };
 enum : uint32_t { H_NONE = 0, H_SPHERE = 1, H_PLANE = 2, H_MESH = 3 };
+enum : uint32_t { PK_NEW_PATH = 0, PK_CLOSEST_DONE = 1, PK_SHADOW_CLEAR = 2, PK_SHADOW_BLOCKED = 3 };
+constexpr uint32_t kPendExit = 0x20000000u;     // XFORM: leave the mesh of node `entered`
 
 struct Lane {
-    // pixel and path
-    Rng rng;
-    uint32_t pI;
-    int sample;
-    uint32_t segments;
-    f3 target, normal, albedo;      // the pixel's three accumulators (renderer/trace.cu:39)
-    f3 contrib;
-    f3 v;                           // -normalised direction of the current segment (trace.cu:86)
+    uint32_t pI;                    // pixel being rendered
+    uint32_t pk;                    // why the lane is in PATH
     // current ray query (closest hit or shadow)
     f3 qpos, qdir, qinv;            // ray in the space it is currently in, and 1/dir
     float limit;                    // slab t_max: FLT_MAX for closest hit, the light distance for shadow rays
@@ -251,7 +257,7 @@ struct Lane {
     uint32_t cur;                   // BVH record to expand
     uint32_t sp;                    // LDS stack height
     uint32_t entered;               // scene node whose mesh is being traversed
-    uint32_t pend;                  // S_LEAF: remaining leaf range; S_ENTER: node | kind << 30
+    uint32_t pend;                  // LEAF: remaining leaf range; XFORM: node | kind << 30, or kPendExit
     bool shadow, trav, mesh_hit;
     // closest hit so far; normal / texture coordinates are derived from (h_*) when the query ends
     float hz;
@@ -260,19 +266,36 @@ struct Lane {
     float h_a, h_b;                 // mesh: barycentrics b1, b2; sphere / plane: local hit x, y
     uint32_t h_c;                   // mesh: triangle record; sphere / plane: bits of local hit z
     bool h_front;
-    // the path while its shadow query runs
-    f3 ndir, nee;
-    bool nee_valid, path_alive;
 };
+
+// Path state that only the PATH operation touches lives in global memory (one column per thread,
+// field-major so that a wave's access to one field is contiguous) instead of being carried in
+// registers through every turn of the scheduler loop: random state, throughput, view vector, the
+// continuation ray and the pending light sample of a path whose shadow query is running.
+enum : uint32_t {
+    C_RNG = 0,        // 6 words
+    C_CONTRIB = 6,    // 3
+    C_V = 9,          // 3
+    C_NDIR = 12,      // 3
+    C_NEE = 15,       // 3
+    C_SAMPLE = 18, C_SEGMENTS = 19, C_FLAGS = 20,
+    C_WORDS = 21
+};
+
+DEV void acc_add(float* __restrict__ p, f3 v) {
+    p[0] += v.x; p[1] += v.y; p[2] += v.z;
+}
 
 // ------------------------------------------------------------------ the scheduled path tracer
 template <bool kCount, bool kPrimary>
 __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPartition P, int samples,
-                                                          const uint32_t* __restrict__ jump,
-                                                          uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
-                                                          int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
-                                                          float* __restrict__ out_t) {
+                                                             const uint32_t* __restrict__ jump,
+                                                             uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
+                                                             int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
+                                                             float* __restrict__ out_t, uint32_t* __restrict__ cold) {
     extern __shared__ uint32_t lds[];
+    __shared__ unsigned long long sect_clock[4], path_sections[32];      // counted build only
+    if (kCount) { if (threadIdx.x < 32) path_sections[threadIdx.x] = 0; __syncthreads(); }
     uint32_t* __restrict__ stack_ref = lds;
     float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * CRT_BLOCK);
     const uint32_t tid = threadIdx.x;
@@ -288,53 +311,24 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPart
     Lane L = {};
     uint32_t state = S_FETCH;
     bool queue_empty = false;
+    const uint32_t cold_stride = gridDim.x * CRT_BLOCK;
+    uint32_t* __restrict__ my_cold = cold + (blockIdx.x * CRT_BLOCK + tid);
+    auto cold_ld = [&](uint32_t f) -> uint32_t { return my_cold[(size_t)f * cold_stride]; };
+    auto cold_st = [&](uint32_t f, uint32_t v) { my_cold[(size_t)f * cold_stride] = v; };
+    auto cold_ld3 = [&](uint32_t f) -> f3 { return mk3(__uint_as_float(cold_ld(f)), __uint_as_float(cold_ld(f + 1)), __uint_as_float(cold_ld(f + 2))); };
+    auto cold_st3 = [&](uint32_t f, f3 v) { cold_st(f, __float_as_uint(v.x)); cold_st(f + 1, __float_as_uint(v.y)); cold_st(f + 2, __float_as_uint(v.z)); };
 
-    // ---- transitions -----------------------------------------------------------------------
-    auto end_path = [&]() -> uint32_t {
-        if (++L.sample >= samples) {
-            if (!kPrimary) {
-                float* r = S.results + 3ull * L.pI;
-                float* nn = S.normals + 3ull * L.pI;
-                float* al = S.albedos + 3ull * L.pI;
-                r[0] = L.target.x; r[1] = L.target.y; r[2] = L.target.z;
-                nn[0] = L.normal.x; nn[1] = L.normal.y; nn[2] = L.normal.z;
-                al[0] = L.albedo.x; al[1] = L.albedo.y; al[2] = L.albedo.z;
-            }
-            return S_FETCH;
-        }
-        return S_CAMERA;
-    };
-    // TraceThroughScene prologue (renderer/trace.cu:44-50); qpos / qdir hold the path ray
-    auto start_closest = [&]() -> uint32_t {
-        L.v = -normalized(L.qdir);
-        L.qpos += L.qdir * CRT_BIAS;
-        L.qinv = recip3(L.qdir);
-        L.limit = CRT_BIGFLOAT;
-        L.shadow = false; L.trav = false; L.node = 0;
-        L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
-        tally.closest_rays++;
-        return S_BOX;
-    };
-    auto continue_path = [&]() -> uint32_t {
-        if (!L.path_alive) return end_path();
-        L.qpos = L.hpos;
-        L.qdir = L.ndir;
-        return start_closest();
-    };
-    // end of TraceShadowRay: add the light sample if nothing was in the way (trace.cu:137-143)
-    auto finish_shadow = [&](bool occluded) -> uint32_t {
-        if (!occluded && L.nee_valid) L.target += L.nee;
-        return continue_path();
-    };
-    auto finish_query = [&]() -> uint32_t { return L.shadow ? finish_shadow(false) : (uint32_t)S_SHADE; };
-    auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_BOX : finish_query(); };
+    // the query has run out of scene nodes
+    auto query_done = [&]() -> uint32_t { L.pk = L.shadow ? PK_SHADOW_CLEAR : PK_CLOSEST_DONE; return S_PATH; };
+    auto shadow_blocked = [&]() -> uint32_t { L.pk = PK_SHADOW_BLOCKED; return S_PATH; };
+    auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_BOX : query_done(); };
 
     // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
     // (MeshObject::Traverse / TraverseShadow loop heads, scene/objects.cu:184-196, 231-242)
     auto resolve = [&](bool have_next, uint32_t next_ref, float next_t) -> uint32_t {
         for (;;) {
             if (!have_next) {
-                if (L.sp == 0) return S_EXIT;
+                if (L.sp == 0) { L.pend = kPendExit; return S_XFORM; }
                 L.sp--;
                 next_ref = stack_ref[L.sp * CRT_BLOCK + tid];
                 next_t = stack_t[L.sp * CRT_BLOCK + tid];
@@ -349,9 +343,8 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPart
         }
     };
 
-    // ---- operations ------------------------------------------------------------------------
-    // one box-pair record, two slab tests: scene-node scan (trace.cu:51-68, 166-193) or BVH
-    // interior node (objects.cu:198-218, 244-264)
+    // ---- BOX: one box-pair record, two slab tests: scene-node scan (trace.cu:51-68, 166-193) or
+    // BVH interior node (objects.cu:198-218, 244-264)
     auto op_box = [&]() -> uint32_t {
         const uint32_t rec_idx = L.trav ? L.cur : L.node;
         const float4* rp = reinterpret_cast<const float4*>(pairs + rec_idx);
@@ -374,34 +367,29 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPart
             L.sp++;
             return resolve(true, a_near ? ref_a : ref_b, fminf(tA, tB));
         }
-        // scan: node `node` is half A, node + 1 is half B
-        uint32_t enter_node = kRefNone, enter_kind = 0;
-        const uint32_t kind_a = node_ref_kind(ref_a);
-        uint32_t nxt = L.node + 1;
-        if (kind_a != CRT_OBJ_NONE) {
-            TALLY(node_box_tests);
-            if (L.shadow) {
-                if (hitA) { enter_node = L.node; enter_kind = kind_a; }
-                else nxt = node_ref_after(ref_a);              // skip the subtree (trace.cu:171-185)
-            } else if (hitA && tA < L.hz) { enter_node = L.node; enter_kind = kind_a; }
+        // scan: node `node` is half A, node + 1 is half B.  Closest hit enters a node whose box is
+        // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
+        // subtree of a node with an object whose box it misses (trace.cu:171-185).
+        const uint32_t kind_a = node_ref_kind(ref_a), kind_b = node_ref_kind(ref_b);
+        const bool obj_a = kind_a != CRT_OBJ_NONE, obj_b = kind_b != CRT_OBJ_NONE;
+        const bool pass_a = L.shadow ? hitA : (hitA && tA < L.hz);
+        const bool pass_b = L.shadow ? hitB : (hitB && tB < L.hz);
+        const bool enter_a = obj_a && pass_a;
+        const uint32_t next_a = (L.shadow && obj_a) ? node_ref_after(ref_a) : L.node + 1;
+        const bool look_b = !enter_a && next_a == L.node + 1 && L.node + 1 < node_count;
+        const bool enter_b = look_b && obj_b && pass_b;
+        const uint32_t next_b = (L.shadow && obj_b) ? node_ref_after(ref_b) : L.node + 2;
+        if (kCount) { tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b && obj_b) ? 1u : 0u); }
+        if (enter_a || enter_b) {
+            L.pend = enter_a ? (L.node | (kind_a << 30)) : ((L.node + 1) | (kind_b << 30));
+            return S_XFORM;
         }
-        if (enter_node == kRefNone && nxt == L.node + 1 && nxt < node_count) {
-            const uint32_t kind_b = node_ref_kind(ref_b);
-            nxt = L.node + 2;
-            if (kind_b != CRT_OBJ_NONE) {
-                TALLY(node_box_tests);
-                if (L.shadow) {
-                    if (hitB) { enter_node = L.node + 1; enter_kind = kind_b; }
-                    else nxt = node_ref_after(ref_b);
-                } else if (hitB && tB < L.hz) { enter_node = L.node + 1; enter_kind = kind_b; }
-            }
-        }
-        if (enter_node != kRefNone) { L.pend = enter_node | (enter_kind << 30); return S_ENTER; }
-        L.node = nxt;
+        L.node = look_b ? next_b : next_a;
         return after_scan();
     };
 
-    // one triangle of the pending leaf (IntersectTriangle / IntersectShadowTriangle, objects.cu:270-366)
+    // ---- LEAF: one triangle of the pending leaf (IntersectTriangle / IntersectShadowTriangle,
+    // objects.cu:270-366)
     auto op_leaf = [&]() -> uint32_t {
         const uint32_t slot = leaf_start(L.pend), left = leaf_count(L.pend) - 1;
         L.pend = make_leaf_ref(slot + 1, left);
@@ -427,7 +415,7 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPart
         const float ndot = dot(cross(edge1, edge2), L.qdir);
         ok = ok && ((ndot < CRT_TRI_EPS) || (ndot > -CRT_TRI_EPS));
         if (ok) {
-            if (L.shadow) return finish_shadow(true);
+            if (L.shadow) return shadow_blocked();
             TALLY(tri_hits);
             L.hz = t;
             L.mesh_hit = true;
@@ -437,358 +425,428 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPart
         return resolve(false, 0, 0);
     };
 
-    // enter a scene node: Node::ToLocal, then the sphere / plane test in place or the start of a
-    // BVH walk (trace.cu:61-66, 188-191; objects.cu:7-159)
-    auto op_enter = [&]() -> uint32_t {
-        const uint32_t enter_node = L.pend & 0x3fffffffu, kind = L.pend >> 30;
-        TALLY(node_enters);
-        const NodeXf* __restrict__ xf = S.xf + enter_node;
-        L.qpos = xform_point(xf->itm, L.qpos);
-        L.qdir = xform_dir(xf->itm, L.qdir);
-        if (kind == CRT_OBJ_MESH) {
-            L.qinv = recip3(L.qdir);
-            L.trav = true; L.entered = enter_node; L.sp = 0; L.mesh_hit = false;
-            return resolve(true, xf->root_ref, 0.0f);
-        }
-        const f3 pos = L.qpos, dir = L.qdir;
-        bool got = false, front = true;
-        float t = 0;
-        if (kind == CRT_OBJ_SPHERE) {
-            TALLY(sphere_tests);
-            if (!(dot(dir, pos) >= 0)) {
-                const float a = dot(dir, dir);
-                const float b = dot(dir, pos) * 2;
-                const float c = dot(pos, pos) - 1;
-                const float det = b * b - 4 * a * c;
-                if (!(det < 0)) {
-                    const float sq = sqrtf(det);
-                    const float tf = (-b - sq) / (2 * a);
-                    const float tb = (-b + sq) / (2 * a);
-                    if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
-                    else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
-                    else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
-                }
-            }
+    // ---- XFORM: enter a scene node (Node::ToLocal, then the sphere / plane test in place or the
+    // start of a BVH walk: trace.cu:61-66, 188-191; objects.cu:7-159) or leave a mesh (world
+    // position of its hit, Node::FromLocal for the ray: trace.cu:64-66, 191)
+    auto op_xform = [&]() -> uint32_t {
+        const bool leaving = L.pend == kPendExit;
+        const uint32_t idx = leaving ? L.entered : (L.pend & 0x1fffffffu);
+        const uint32_t kind = L.pend >> 30;
+        const NodeXf* __restrict__ xf = S.xf + idx;
+        if (leaving) {
+            if (L.mesh_hit) L.hpos = xform_point(xf->tm, L.qpos + L.hz * L.qdir);
+            L.trav = false;
         } else {
-            TALLY(plane_tests);
-            if (!(dir.z == 0)) {
-                t = -pos.z / dir.z;
-                const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
-                if (in_range && ((dir.z < 0) || (dir.z > 0))) {
-                    const f3 p = pos + t * dir;
-                    if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
+            TALLY(node_enters);
+            L.qpos = xform_point(xf->itm, L.qpos);
+            L.qdir = xform_dir(xf->itm, L.qdir);
+            if (kind == CRT_OBJ_MESH) {
+                L.qinv = recip3(L.qdir);
+                L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
+                return resolve(true, xf->root_ref, 0.0f);
+            }
+            const f3 pos = L.qpos, dir = L.qdir;
+            bool got = false, front = true;
+            float t = 0;
+            if (kind == CRT_OBJ_SPHERE) {
+                TALLY(sphere_tests);
+                if (!(dot(dir, pos) >= 0)) {
+                    const float a = dot(dir, dir);
+                    const float b = dot(dir, pos) * 2;
+                    const float c = dot(pos, pos) - 1;
+                    const float det = b * b - 4 * a * c;
+                    if (!(det < 0)) {
+                        const float sq = sqrtf(det);
+                        const float tf = (-b - sq) / (2 * a);
+                        const float tb = (-b + sq) / (2 * a);
+                        if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
+                        else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
+                        else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
+                    }
                 }
-            }
-        }
-        if (got) {
-            if (L.shadow) return finish_shadow(true);
-            const f3 p = pos + t * dir;
-            L.hz = t;
-            L.hpos = xform_point(xf->tm, p);
-            L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
-            L.h_node = enter_node; L.h_front = front;
-            L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
-        }
-        L.qpos = xform_point(xf->tm, L.qpos);
-        L.qdir = xform_dir(xf->tm, L.qdir);
-        L.qinv = recip3(L.qdir);
-        L.node = enter_node + 1;
-        return after_scan();
-    };
-
-    // leave a mesh: world position of its hit, Node::FromLocal for the ray (trace.cu:64-66, 191)
-    auto op_exit = [&]() -> uint32_t {
-        const NodeXf* __restrict__ xf = S.xf + L.entered;
-        if (L.mesh_hit) L.hpos = xform_point(xf->tm, L.qpos + L.hz * L.qdir);
-        L.qpos = xform_point(xf->tm, L.qpos);
-        L.qdir = xform_dir(xf->tm, L.qdir);
-        L.qinv = recip3(L.qdir);
-        L.trav = false;
-        L.node = L.entered + 1;
-        return after_scan();
-    };
-
-    // a new path: camera ray (trace.cu:26-38)
-    auto op_camera = [&]() -> uint32_t {
-        const uint32_t pY = L.pI / S.width, pX = L.pI - pY * S.width;
-        camera_ray(S, pX, pY, L.rng, L.qpos, L.qdir);
-        L.contrib = mk3(1, 1, 1) * inv_samples;
-        L.segments = 0;
-        TALLY(paths);
-        return start_closest();
-    };
-
-    // the closest-hit query has ended: lights, then TracePath's body (trace.cu:72-78, 91-157)
-    auto op_shade = [&]() -> uint32_t {
-        // lights are intersected last, with the ray as the node loop left it
-        int hit_light = -1;
-        f3 light_n = mk3(0, 0, 0);
-        for (uint32_t i = 0; i < S.light_count; i++) {
-            const DevLight Li = S.lights[i];
-            if (Li.kind != CRT_LIGHT_POINT) continue;
-            // PointLight::Intersect (scene/lights.cu:36-89)
-            const f3 lp = ld3(Li.pos);
-            const f3 o = L.qpos - lp;
-            const float a = dot(L.qdir, L.qdir);
-            const float b = dot(2 * L.qdir, o);
-            const float c = dot(o, o) - Li.size * Li.size;
-            const float det = b * b - 4 * a * c;
-            if (det < 0) continue;
-            const float sq = sqrtf(det);
-            const float tf = (-b - sq) / (2 * a);
-            const float tb = (-b + sq) / (2 * a);
-            if (tf >= 0) {
-                if (tf >= L.hz) continue;
-                L.hz = tf;
-                light_n = normalized(o);
-                L.hpos = L.qpos + tf * L.qdir;
-                hit_light = (int)i;
-                continue;
-            }
-            if (tb < 0) continue;
-            if (tb >= L.hz) continue;
-            L.hz = tb;
-            light_n = normalized(L.hpos);          // the previous hit position, as the reference reads it (lights.cu:78)
-            L.hpos = L.qpos + tb * L.qdir;
-            hit_light = (int)i;
-        }
-        const bool any = hit_light >= 0 || L.h_kind != H_NONE;
-
-        if (kPrimary) {
-            int32_t id = -1, face = -1;
-            if (hit_light >= 0) id = -2 - hit_light;
-            else if (any) { id = (int32_t)L.h_node; if (L.h_kind == H_MESH) face = (int32_t)tris[L.h_c].face; }
-            out_node[L.pI] = id; out_face[L.pI] = face; out_t[L.pI] = L.hz;
-            return end_path();
-        }
-
-        if (!any) {
-            const f3 env = tex_env<kCount>(S, L.qdir, tally);
-            L.target += L.contrib * env;
-            L.normal += L.contrib * normalized(L.qdir);
-            L.albedo += L.contrib * env;
-            return end_path();
-        }
-        if (hit_light >= 0) {
-            const f3 rad = ld3(S.lights[hit_light].radiance);
-            L.target += L.contrib * rad;
-            L.normal += L.contrib * light_n;
-            L.albedo += L.contrib * rad;
-            return end_path();
-        }
-
-        // normal and texture coordinates of the hit (objects.cu:44-50, 126-131, 308-320) and
-        // Node::FromLocal for the normal (scene/scene.cuh:185-189)
-        const NodeXf* __restrict__ xf = S.xf + L.h_node;
-        f3 n, uvw;
-        if (L.h_kind == H_MESH) {
-            const float4* tp = reinterpret_cast<const float4*>(tris + L.h_c);
-            const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-            const f3 p0 = mk3(v0.x, v0.y, v0.z);
-            const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
-            const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
-            const uint32_t face = __float_as_uint(v0.w);
-            const float b1 = L.h_a, b2 = L.h_b;
-            const float b0 = 1 - b2 - b1;
-            const DevMesh M = S.meshes[xf->mesh_id];
-            if (!M.has_normals) n = normalized(cross(edge1, edge2));
-            else {
-                const uint32_t i0 = M.fn[3 * face], i1 = M.fn[3 * face + 1], i2 = M.fn[3 * face + 2];
-                n = ld3(M.vn + 3 * i0) * b0 + ld3(M.vn + 3 * i1) * b1 + ld3(M.vn + 3 * i2) * b2;
-            }
-            if (!M.has_tex) uvw = mk3(0, 0, 0);
-            else {
-                const uint32_t i0 = M.ft[3 * face], i1 = M.ft[3 * face + 1], i2 = M.ft[3 * face + 2];
-                uvw = ld3(M.vt + 3 * i0) * b0 + ld3(M.vt + 3 * i1) * b1 + ld3(M.vt + 3 * i2) * b2;
-            }
-        } else {
-            const f3 p = mk3(L.h_a, L.h_b, __uint_as_float(L.h_c));
-            if (L.h_kind == H_SPHERE) {
-                n = p;
-                uvw = mk3(0.5f * 0.318309f * crtm::det_atan2f(p.y, p.x) + 0.5f,
-                          0.318309f * crtm::det_asinf(fminf(fmaxf(p.z, -1.0f), 1.0f)) + 0.5f, 0);
             } else {
-                n = mk3(0, 0, 1);
-                uvw = 0.5f * (p + mk3(1, 1, 0));
+                TALLY(plane_tests);
+                if (!(dir.z == 0)) {
+                    t = -pos.z / dir.z;
+                    const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
+                    if (in_range && ((dir.z < 0) || (dir.z > 0))) {
+                        const f3 p = pos + t * dir;
+                        if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
+                    }
+                }
+            }
+            if (got) {
+                if (L.shadow) return shadow_blocked();
+                const f3 p = pos + t * dir;
+                L.hz = t;
+                L.hpos = xform_point(xf->tm, p);
+                L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
+                L.h_node = idx; L.h_front = front;
+                L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
             }
         }
-        n = xform_normal(xf->itm, n);
-        const f3 hpos = L.hpos;
-        const f3 v = L.v;
+        L.qpos = xform_point(xf->tm, L.qpos);
+        L.qdir = xform_dir(xf->tm, L.qdir);
+        L.qinv = recip3(L.qdir);
+        L.node = idx + 1;
+        return after_scan();
+    };
 
-        const float light_pick = rng_float(L.rng);
-        const DevMaterial mtl = S.materials[xf->material_id];
-        const f3 kD = tex_eval<kCount>(S, mtl.diffuse, uvw, tally);
-        const f3 kS = tex_eval<kCount>(S, mtl.specular, uvw, tally);
-        const f3 kT = tex_eval<kCount>(S, mtl.refraction, uvw, tally);
-        const f3 kE = tex_eval<kCount>(S, mtl.emission, uvw, tally);
-        L.normal += L.contrib * n;
-        L.albedo += L.contrib * kD + kE;
-        L.target += L.contrib * kE;
-
-        // lobe probabilities (renderer/shading.cu:17-29 and 122-134)
-        const float third = 1.0f / 3.0f;
-        float pD = (kD.x + kD.y + kD.z) * third;
-        float pS = (kS.x + kS.y + kS.z) * third;
-        float pT = (kT.x + kT.y + kT.z) * third;
-        if (pD + pS + pT > CRT_MAX_SURVIVAL) {
-            const float norm = CRT_MAX_SURVIVAL / (pD + pS + pT);
-            pD *= norm; pS *= norm; pT *= norm;
-        }
-        const float g = mtl.glossiness;
-
-        // next-event estimation toward one light (trace.cu:112-143).  Ambient and directional
-        // lights produce no sample and zero weight, so nothing is traced for them; with no light
-        // at all (where the reference reads a null light) no sample is taken either.
-        bool want_shadow = false;
+    // ---- PATH: everything between two ray queries of a pixel (TracePath, trace.cu:83-158)
+    auto op_path = [&]() -> uint32_t {
+        bool want_shadow = false, alive = false;
         f3 spos = mk3(0, 0, 0), sdir = mk3(0, 0, 1);
         float sdist = 0;
-        L.nee_valid = false;
-        if (S.light_count > 0) {
-            const int light_id = crtm::f2i_sat(light_pick * (float)S.light_count);
-            const DevLight Ls = S.lights[light_id];
-            if (Ls.kind == CRT_LIGHT_POINT) {
-                // PointLight::GenerateSample (scene/lights.cu:10-34)
-                const f3 lp = ld3(Ls.pos);
-                const f3 Ldir = normalized(hpos - lp);
-                const float x = rng_float(L.rng);
-                const float phi = rng_float(L.rng) * 2 * F_PI;
-                const float cos_theta = 1 - x;
-                const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-                f3 a, b;
-                orthonormals(Ldir, a, b);
-                const f3 ln = Ldir * cos_theta + a * sin_theta * crtm::det_cosf(phi) + b * sin_theta * crtm::det_sinf(phi);
-                const f3 tgt = lp + ln * Ls.size;
-                const f3 ldir = normalized(tgt - hpos);
-                const float d2 = lengthsq(tgt - hpos);
-                const float cos_theta_l = dot(ldir, -normalized(tgt - lp));
-                const float l_prob = d2 / (2 * F_PI * Ls.size * Ls.size * cos_theta_l);
-                const f3 l_mult = ld3(Ls.radiance);
-                sdist = sqrtf(d2);
-                // Material::GetSampleInfo (renderer/shading.cu:116-150)
-                float b_prob = 0.0f;
-                f3 b_mult = mk3(0, 0, 0);
-                const float ndl = dot(n, ldir);
-                if (ndl >= 0) {
-                    b_prob += pD * (ndl > 0 ? OVERPI : 0);
-                    b_mult += kD * OVERPI * ndl;
-                    const f3 rn = normalized(v + ldir);
-                    const float ndh = dot(n, rn);
-                    b_prob += pS * (g + 1) * 0.5f * OVERPI * crtm::det_powf(ndh, g + 1);
-                    b_mult += kS * (g + 2) * 0.125f * OVERPI * crtm::det_powf(ndh, g);
+        // the pixel's three accumulators are updated in place (renderer/trace.cu:39, 92-141)
+        float* __restrict__ acc_target = S.results + 3ull * L.pI;
+        float* __restrict__ acc_normal = S.normals + 3ull * L.pI;
+        float* __restrict__ acc_albedo = S.albedos + 3ull * L.pI;
+        // Section clock of the counted build: one stamp per wave in LDS, advanced by the first active
+        // lane, so that a section's cycles are counted once per turn whichever lanes run it.
+        if (kCount && lane_rank(__ballot(true)) == 0) sect_clock[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+#define SECT(i) do { if (kCount && lane_rank(__ballot(true)) == 0) { \
+            const unsigned long long t_n = __builtin_amdgcn_s_memtime(); \
+            path_sections[(threadIdx.x >> 6) * 8 + i] += t_n - sect_clock[threadIdx.x >> 6]; sect_clock[threadIdx.x >> 6] = t_n; } } while (0)
+        Rng rng;
+        rng.d = cold_ld(C_RNG); rng.v0 = cold_ld(C_RNG + 1); rng.v1 = cold_ld(C_RNG + 2);
+        rng.v2 = cold_ld(C_RNG + 3); rng.v3 = cold_ld(C_RNG + 4); rng.v4 = cold_ld(C_RNG + 5);
+        f3 contrib = cold_ld3(C_CONTRIB);
+        int sample = (int)cold_ld(C_SAMPLE);
+        uint32_t segments = cold_ld(C_SEGMENTS);
+        f3 next_dir = mk3(0, 0, 1);
+
+        if (L.pk == PK_SHADOW_CLEAR || L.pk == PK_SHADOW_BLOCKED) {
+            // end of TraceShadowRay: add the light sample if nothing was in the way (trace.cu:137-143)
+            const uint32_t flags = cold_ld(C_FLAGS);
+            if (L.pk == PK_SHADOW_CLEAR && (flags & 1u)) acc_add(acc_target, cold_ld3(C_NEE));
+            alive = (flags & 2u) != 0;
+            next_dir = cold_ld3(C_NDIR);
+        } else if (L.pk == PK_CLOSEST_DONE) {
+            // lights are intersected last, with the ray as the node loop left it (trace.cu:72-78)
+            int hit_light = -1;
+            f3 light_n = mk3(0, 0, 0);
+            for (uint32_t i = 0; i < S.light_count; i++) {
+                const DevLight Li = S.lights[i];
+                if (Li.kind != CRT_LIGHT_POINT) continue;
+                // PointLight::Intersect (scene/lights.cu:36-89)
+                const f3 lp = ld3(Li.pos);
+                const f3 o = L.qpos - lp;
+                const float a = dot(L.qdir, L.qdir);
+                const float b = dot(2 * L.qdir, o);
+                const float c = dot(o, o) - Li.size * Li.size;
+                const float det = b * b - 4 * a * c;
+                if (det < 0) continue;
+                const float sq = sqrtf(det);
+                const float tf = (-b - sq) / (2 * a);
+                const float tb = (-b + sq) / (2 * a);
+                if (tf >= 0) {
+                    if (tf >= L.hz) continue;
+                    L.hz = tf;
+                    light_n = normalized(o);
+                    L.hpos = L.qpos + tf * L.qdir;
+                    hit_light = (int)i;
+                    continue;
                 }
-                const float denom = l_prob * l_prob + b_prob * b_prob;
-                if (denom > CRT_F_EPS && l_prob > CRT_F_EPS) {
-                    const float pop = l_prob / denom;
-                    L.nee = L.contrib * l_mult * b_mult * pop;
-                    L.nee_valid = true;
+                if (tb < 0) continue;
+                if (tb >= L.hz) continue;
+                L.hz = tb;
+                light_n = normalized(L.hpos);      // the previous hit position, as the reference reads it (lights.cu:78)
+                L.hpos = L.qpos + tb * L.qdir;
+                hit_light = (int)i;
+            }
+            const bool any = hit_light >= 0 || L.h_kind != H_NONE;
+            SECT(0);
+
+            if (kPrimary) {
+                int32_t id = -1, face = -1;
+                if (hit_light >= 0) id = -2 - hit_light;
+                else if (any) { id = (int32_t)L.h_node; if (L.h_kind == H_MESH) face = (int32_t)tris[L.h_c].face; }
+                out_node[L.pI] = id; out_face[L.pI] = face; out_t[L.pI] = L.hz;
+            } else if (!any) {
+                const f3 env = tex_env<kCount>(S, L.qdir, tally);
+                acc_add(acc_target, contrib * env);
+                acc_add(acc_normal, contrib * normalized(L.qdir));
+                acc_add(acc_albedo, contrib * env);
+            } else if (hit_light >= 0) {
+                const f3 rad = ld3(S.lights[hit_light].radiance);
+                acc_add(acc_target, contrib * rad);
+                acc_add(acc_normal, contrib * light_n);
+                acc_add(acc_albedo, contrib * rad);
+            } else {
+                // normal and texture coordinates of the hit (objects.cu:44-50, 126-131, 308-320) and
+                // Node::FromLocal for the normal (scene/scene.cuh:185-189)
+                const NodeXf* __restrict__ xf = S.xf + L.h_node;
+                f3 n, uvw;
+                if (L.h_kind == H_MESH) {
+                    const float4* tp = reinterpret_cast<const float4*>(tris + L.h_c);
+                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                    const f3 p0 = mk3(v0.x, v0.y, v0.z);
+                    const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
+                    const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
+                    const uint32_t face = __float_as_uint(v0.w);
+                    const float b1 = L.h_a, b2 = L.h_b;
+                    const float b0 = 1 - b2 - b1;
+                    const DevMesh M = S.meshes[xf->mesh_id];
+                    if (!M.has_normals) n = normalized(cross(edge1, edge2));
+                    else {
+                        const uint32_t i0 = M.fn[3 * face], i1 = M.fn[3 * face + 1], i2 = M.fn[3 * face + 2];
+                        n = ld3(M.vn + 3 * i0) * b0 + ld3(M.vn + 3 * i1) * b1 + ld3(M.vn + 3 * i2) * b2;
+                    }
+                    if (!M.has_tex) uvw = mk3(0, 0, 0);
+                    else {
+                        const uint32_t i0 = M.ft[3 * face], i1 = M.ft[3 * face + 1], i2 = M.ft[3 * face + 2];
+                        uvw = ld3(M.vt + 3 * i0) * b0 + ld3(M.vt + 3 * i1) * b1 + ld3(M.vt + 3 * i2) * b2;
+                    }
+                } else {
+                    const f3 p = mk3(L.h_a, L.h_b, __uint_as_float(L.h_c));
+                    if (L.h_kind == H_SPHERE) {
+                        n = p;
+                        uvw = mk3(0.5f * 0.318309f * crtm::det_atan2f(p.y, p.x) + 0.5f,
+                                  0.318309f * crtm::det_asinf(fminf(fmaxf(p.z, -1.0f), 1.0f)) + 0.5f, 0);
+                    } else {
+                        n = mk3(0, 0, 1);
+                        uvw = 0.5f * (p + mk3(1, 1, 0));
+                    }
                 }
-                // TraceShadowRay prologue (trace.cu:160-162)
-                spos = hpos; sdir = ldir;
-                spos += sdir * CRT_BIAS + n * CRT_BIAS;
-                want_shadow = true;
+                n = xform_normal(xf->itm, n);
+                SECT(1);
+                const f3 hpos = L.hpos;
+                const f3 v = cold_ld3(C_V);
+
+                const float light_pick = rng_float(rng);
+                const DevMaterial mtl = S.materials[xf->material_id];
+                const f3 kD = tex_eval<kCount>(S, mtl.diffuse, uvw, tally);
+                const f3 kS = tex_eval<kCount>(S, mtl.specular, uvw, tally);
+                const f3 kT = tex_eval<kCount>(S, mtl.refraction, uvw, tally);
+                const f3 kE = tex_eval<kCount>(S, mtl.emission, uvw, tally);
+                SECT(2);
+                acc_add(acc_normal, contrib * n);
+                acc_add(acc_albedo, contrib * kD + kE);
+                acc_add(acc_target, contrib * kE);
+
+                // lobe probabilities (renderer/shading.cu:17-29 and 122-134)
+                const float third = 1.0f / 3.0f;
+                float pD = (kD.x + kD.y + kD.z) * third;
+                float pS = (kS.x + kS.y + kS.z) * third;
+                float pT = (kT.x + kT.y + kT.z) * third;
+                if (pD + pS + pT > CRT_MAX_SURVIVAL) {
+                    const float norm = CRT_MAX_SURVIVAL / (pD + pS + pT);
+                    pD *= norm; pS *= norm; pT *= norm;
+                }
+                const float g = mtl.glossiness;
+
+                // next-event estimation toward one light (trace.cu:112-143).  Ambient and directional
+                // lights produce no sample and zero weight, so nothing is traced for them; with no
+                // light at all (where the reference reads a null light) no sample is taken either.
+                bool nee_valid = false;
+                if (S.light_count > 0) {
+                    const int light_id = crtm::f2i_sat(light_pick * (float)S.light_count);
+                    const DevLight Ls = S.lights[light_id];
+                    if (Ls.kind == CRT_LIGHT_POINT) {
+                        // PointLight::GenerateSample (scene/lights.cu:10-34)
+                        const f3 lp = ld3(Ls.pos);
+                        const f3 Ldir = normalized(hpos - lp);
+                        const float x = rng_float(rng);
+                        const float phi = rng_float(rng) * 2 * F_PI;
+                        const float cos_theta = 1 - x;
+                        const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+                        f3 a, b;
+                        orthonormals(Ldir, a, b);
+                        float sin_phi, cos_phi;
+                        crtm::det_sincosf(phi, sin_phi, cos_phi);
+                        const f3 ln = Ldir * cos_theta + a * sin_theta * cos_phi + b * sin_theta * sin_phi;
+                        const f3 tgt = lp + ln * Ls.size;
+                        const f3 ldir = normalized(tgt - hpos);
+                        const float d2 = lengthsq(tgt - hpos);
+                        const float cos_theta_l = dot(ldir, -normalized(tgt - lp));
+                        const float l_prob = d2 / (2 * F_PI * Ls.size * Ls.size * cos_theta_l);
+                        const f3 l_mult = ld3(Ls.radiance);
+                        sdist = sqrtf(d2);
+                        // Material::GetSampleInfo (renderer/shading.cu:116-150)
+                        float b_prob = 0.0f;
+                        f3 b_mult = mk3(0, 0, 0);
+                        const float ndl = dot(n, ldir);
+                        if (ndl >= 0) {
+                            b_prob += pD * (ndl > 0 ? OVERPI : 0);
+                            b_mult += kD * OVERPI * ndl;
+                            const f3 rn = normalized(v + ldir);
+                            const float ndh = dot(n, rn);
+                            b_prob += pS * (g + 1) * 0.5f * OVERPI * crtm::det_powf(ndh, g + 1);
+                            b_mult += kS * (g + 2) * 0.125f * OVERPI * crtm::det_powf(ndh, g);
+                        }
+                        const float denom = l_prob * l_prob + b_prob * b_prob;
+                        if (denom > CRT_F_EPS && l_prob > CRT_F_EPS) {
+                            const float pop = l_prob / denom;
+                            cold_st3(C_NEE, contrib * l_mult * b_mult * pop);
+                            nee_valid = true;
+                        }
+                        // TraceShadowRay prologue (trace.cu:160-162)
+                        spos = hpos; sdir = ldir;
+                        spos += sdir * CRT_BIAS + n * CRT_BIAS;
+                        want_shadow = true;
+                    }
+                }
+
+                SECT(3);
+                // Material::GenerateSample (renderer/shading.cu:11-113)
+                f3 kA = mk3(1, 1, 1);
+                if (!L.h_front) {
+                    const f3 e = ld3(mtl.absorption) * -L.hz;
+                    kA = mk3(crtm::det_expf(e.x), crtm::det_expf(e.y), crtm::det_expf(e.z));
+                }
+                const float p = rng_float(rng);
+                f3 ndir = mk3(0, 0, 0), n_mult = mk3(0, 0, 0);
+                float n_prob = 0;
+                bool sampled = true;
+                if (p < pD) {
+                    const float x = rng_float(rng);
+                    const float phi = rng_float(rng) * 2 * F_PI;
+                    const float cos_theta = 1 - x;
+                    const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+                    f3 u, w;
+                    orthonormals(n, u, w);
+                    float sin_phi, cos_phi;
+                    crtm::det_sincosf(phi, sin_phi, cos_phi);
+                    ndir = n * cos_theta + u * sin_theta * cos_phi + w * sin_theta * sin_phi;
+                    n_prob = pD * OVERPI;
+                    n_mult = kA * kD * OVERPI * dot(n, ndir);
+                } else {
+                    const f3 gln = glossy_normal(n, g, rng);
+                    if (p < pD + pS) {
+                        ndir = reflect(v, gln);
+                        const float pw = crtm::det_powf(dot(gln, n), g);
+                        n_prob = pS * (g + 1) * 0.125f * OVERPI * pw;
+                        n_mult = kA * kS * (g + 2) * 0.125f * OVERPI * pw;
+                    } else if (p < pD + pS + pT) {
+                        const float eta_i = L.h_front ? 1 : mtl.ior;
+                        const float eta_o = L.h_front ? mtl.ior : 1;
+                        const f3 h = L.h_front ? gln : -gln;
+                        bool tir = false;
+                        ndir = transmit(v, h, eta_i, eta_o, tir);
+                        const float f_0 = crtm::det_powf((eta_i - eta_o) / (eta_i + eta_o), 2);
+                        const float cos_theta = dot(v, h);
+                        float f_theta = f_0 + (1 - f_0) * crtm::det_powf(1 - cos_theta, 5);
+                        f_theta = fminf(fmaxf(f_theta, 0.0f), 1.0f);
+                        if (!tir) {
+                            if (rng_float(rng) >= f_theta) {
+                                n_prob = pT * (1 - f_theta);
+                                n_mult = kA * kT * (1 - f_theta);
+                            } else {
+                                ndir = reflect(v, h);
+                                n_prob = pT * f_theta;
+                                n_mult = kA * kT * f_theta;
+                            }
+                        } else {
+                            n_prob = pT;
+                            n_mult = kA * kT;
+                        }
+                    } else {
+                        sampled = false;
+                    }
+                }
+                // the path continues unless the sample died, its probability vanished or the safety bound hit
+                if (sampled) {
+                    next_dir = ndir;
+                    if (!(n_prob <= CRT_F_EPS)) {
+                        contrib *= n_mult * (1.0f / n_prob);
+                        alive = ++segments < CRT_MAX_SEGMENTS;
+                    }
+                }
+                if (want_shadow) {
+                    cold_st3(C_NDIR, next_dir);
+                    cold_st(C_FLAGS, (nee_valid ? 1u : 0u) | (alive ? 2u : 0u));
+                }
             }
         }
 
-        // Material::GenerateSample (renderer/shading.cu:11-113)
-        f3 kA = mk3(1, 1, 1);
-        if (!L.h_front) {
-            const f3 e = ld3(mtl.absorption) * -L.hz;
-            kA = mk3(crtm::det_expf(e.x), crtm::det_expf(e.y), crtm::det_expf(e.z));
-        }
-        const float p = rng_float(L.rng);
-        f3 ndir = mk3(0, 0, 0), n_mult = mk3(0, 0, 0);
-        float n_prob = 0;
-        bool alive = true;
-        if (p < pD) {
-            const float x = rng_float(L.rng);
-            const float phi = rng_float(L.rng) * 2 * F_PI;
-            const float cos_theta = 1 - x;
-            const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-            f3 u, w;
-            orthonormals(n, u, w);
-            ndir = n * cos_theta + u * sin_theta * crtm::det_cosf(phi) + w * sin_theta * crtm::det_sinf(phi);
-            n_prob = pD * OVERPI;
-            n_mult = kA * kD * OVERPI * dot(n, ndir);
-        } else {
-            const f3 gln = glossy_normal(n, g, L.rng);
-            if (p < pD + pS) {
-                ndir = reflect(v, gln);
-                const float pw = crtm::det_powf(dot(gln, n), g);
-                n_prob = pS * (g + 1) * 0.125f * OVERPI * pw;
-                n_mult = kA * kS * (g + 2) * 0.125f * OVERPI * pw;
-            } else if (p < pD + pS + pT) {
-                const float eta_i = L.h_front ? 1 : mtl.ior;
-                const float eta_o = L.h_front ? mtl.ior : 1;
-                const f3 h = L.h_front ? gln : -gln;
-                bool tir = false;
-                ndir = transmit(v, h, eta_i, eta_o, tir);
-                const float f_0 = crtm::det_powf((eta_i - eta_o) / (eta_i + eta_o), 2);
-                const float cos_theta = dot(v, h);
-                float f_theta = f_0 + (1 - f_0) * crtm::det_powf(1 - cos_theta, 5);
-                f_theta = fminf(fmaxf(f_theta, 0.0f), 1.0f);
-                if (!tir) {
-                    if (rng_float(L.rng) >= f_theta) {
-                        n_prob = pT * (1 - f_theta);
-                        n_mult = kA * kT * (1 - f_theta);
-                    } else {
-                        ndir = reflect(v, h);
-                        n_prob = pT * f_theta;
-                        n_mult = kA * kT * f_theta;
-                    }
-                } else {
-                    n_prob = pT;
-                    n_mult = kA * kT;
-                }
-            } else {
-                alive = false;
-            }
-        }
-        // the path continues unless the sample died, its probability vanished or the safety bound hit
-        L.path_alive = false;
-        if (alive) {
-            L.ndir = ndir;
-            if (!(n_prob <= CRT_F_EPS)) {
-                L.contrib *= n_mult * (1.0f / n_prob);
-                L.path_alive = ++L.segments < CRT_MAX_SEGMENTS;
-            }
-        }
+        SECT(4);
+        // ---- what comes next for this pixel
+        uint32_t next_state = S_BOX;
         if (want_shadow) {
             tally.shadow_rays++;
             L.qpos = spos; L.qdir = sdir; L.qinv = recip3(sdir);
             L.limit = sdist;
             L.shadow = true; L.trav = false; L.node = 0;
-            return S_BOX;
+        } else {
+            bool have_ray = true;
+            if (alive) {
+                L.qpos = L.hpos;
+                L.qdir = next_dir;
+            } else if (L.pk != PK_NEW_PATH && ++sample >= samples) {
+                have_ray = false;
+                next_state = S_FETCH;
+            } else {
+                // a new path: camera ray (trace.cu:26-38)
+                const uint32_t pY = L.pI / S.width, pX = L.pI - pY * S.width;
+                camera_ray(S, pX, pY, rng, L.qpos, L.qdir);
+                contrib = mk3(1, 1, 1) * inv_samples;
+                segments = 0;
+                TALLY(paths);
+            }
+            if (have_ray) {
+                // TraceThroughScene prologue (renderer/trace.cu:44-50)
+                cold_st3(C_V, -normalized(L.qdir));
+                L.qpos += L.qdir * CRT_BIAS;
+                L.qinv = recip3(L.qdir);
+                L.limit = CRT_BIGFLOAT;
+                L.shadow = false; L.trav = false; L.node = 0;
+                L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
+                tally.closest_rays++;
+            }
         }
-        return continue_path();
+        cold_st(C_RNG, rng.d); cold_st(C_RNG + 1, rng.v0); cold_st(C_RNG + 2, rng.v1);
+        cold_st(C_RNG + 3, rng.v2); cold_st(C_RNG + 4, rng.v3); cold_st(C_RNG + 5, rng.v4);
+        cold_st3(C_CONTRIB, contrib);
+        cold_st(C_SAMPLE, (uint32_t)sample);
+        cold_st(C_SEGMENTS, segments);
+        SECT(5);
+        return next_state;
     };
 
     // ---- the scheduler ---------------------------------------------------------------------
     for (;;) {
-        // Which operation runs this turn: box steps while at least sched_box_min lanes want one,
-        // otherwise whatever the largest number of lanes is waiting for.
-        uint32_t best = S_BOX;
-        if ((uint32_t)__popcll(__ballot(state == S_BOX)) < S.sched_box_min) {
-            uint32_t best_n = 0;
-            best = S_DONE;
-#pragma unroll
-            for (uint32_t s = 0; s < S_DONE; s++) {
-                const uint32_t n = (uint32_t)__popcll(__ballot(state == s));
-                if (n > best_n) { best_n = n; best = s; }
-            }
-            if (best == S_DONE) break;
+        // Which operation runs this turn.  Box steps are the bulk of the work and run whenever
+        // sched_box_min lanes want one.  Otherwise a cheap traversal operation (triangle, transform)
+        // runs once sched_special_min lanes wait for it; failing that the fuller of box / path /
+        // fetch; leftovers last.
+        uint32_t n_box = (uint32_t)__popcll(__ballot(state == S_BOX));
+        // box burst: this inner loop carries only the few values a box step changes
+        while (n_box >= S.sched_box_min) {
+            unsigned long long t_box = 0;
+            if (kCount) { t_box = __builtin_amdgcn_s_memtime(); tally.turns[0]++; tally.lanes[0] += state == S_BOX; }
+            if (state == S_BOX) state = op_box();
+            if (kCount) tally.cycles[0] += __builtin_amdgcn_s_memtime() - t_box;
+            n_box = (uint32_t)__popcll(__ballot(state == S_BOX));
         }
+        uint32_t best = S_BOX;
+        {
+            const uint32_t n_leaf = (uint32_t)__popcll(__ballot(state == S_LEAF));
+            const uint32_t n_xf = (uint32_t)__popcll(__ballot(state == S_XFORM));
+            const uint32_t n_path = (uint32_t)__popcll(__ballot(state == S_PATH));
+            const uint32_t n_fetch = (uint32_t)__popcll(__ballot(state == S_FETCH));
+            const uint32_t special = n_leaf >= n_xf ? (uint32_t)S_LEAF : (uint32_t)S_XFORM;
+            const uint32_t n_special = n_leaf >= n_xf ? n_leaf : n_xf;
+            const uint32_t heavy = n_path >= n_fetch ? (uint32_t)S_PATH : (uint32_t)S_FETCH;
+            const uint32_t n_heavy = n_path >= n_fetch ? n_path : n_fetch;
+            if (n_special >= S.sched_special_min) best = special;
+            else if (n_box > 0 && n_box >= n_heavy) best = S_BOX;
+            else if (n_heavy >= S.sched_heavy_min || (n_heavy > 0 && n_box == 0 && n_special == 0)) best = heavy;
+            else if (n_special > 0) best = special;
+            else if (n_box > 0) best = S_BOX;
+            else if (n_heavy > 0) best = heavy;
+            else break;
+        }
+        unsigned long long t_start = 0;
+        if (kCount) t_start = __builtin_amdgcn_s_memtime();
         switch (best) {
             case S_BOX: if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; } if (state == S_BOX) state = op_box(); break;
             case S_LEAF: if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); break;
-            case S_ENTER: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_ENTER; } if (state == S_ENTER) state = op_enter(); break;
-            case S_EXIT: if (kCount) { tally.turns[3]++; tally.lanes[3] += state == S_EXIT; } if (state == S_EXIT) state = op_exit(); break;
-            case S_SHADE: if (kCount) { tally.turns[4]++; tally.lanes[4] += state == S_SHADE; } if (state == S_SHADE) state = op_shade(); break;
-            case S_CAMERA: if (kCount) { tally.turns[5]++; tally.lanes[5] += state == S_CAMERA; } if (state == S_CAMERA) state = op_camera(); break;
+            case S_XFORM: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_XFORM; } if (state == S_XFORM) state = op_xform(); break;
+            case S_PATH: if (kCount) { tally.turns[3]++; tally.lanes[3] += state == S_PATH; } if (state == S_PATH) state = op_path(); break;
             default: {
-                // S_FETCH: idle lanes take consecutive items from the pixel queue with one atomic per wave
+                // FETCH: idle lanes take consecutive items from the pixel queue with one atomic per wave
                 const bool need = state == S_FETCH;
-                if (kCount) { tally.turns[6]++; tally.lanes[6] += need; }
+                if (kCount) { tally.turns[4]++; tally.lanes[4] += need; }
                 const unsigned long long mask = __ballot(need);
                 if (queue_empty) { if (need) state = S_DONE; break; }
                 uint32_t base = 0;
@@ -802,18 +860,21 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPart
                     if (item >= P.total_items) state = S_DONE;
                     else if (item_to_pixel(S, P, item, pX, pY)) {
                         L.pI = pY * S.width + pX;
-                        rng_init(L.rng, L.pI, jump);
-                        if (!kPrimary) {
-                            L.target = ld3(S.results + 3ull * L.pI);
-                            L.normal = ld3(S.normals + 3ull * L.pI);
-                            L.albedo = ld3(S.albedos + 3ull * L.pI);
-                        }
-                        L.sample = 0;
-                        state = S_CAMERA;
+                        Rng rng;
+                        rng_init(rng, L.pI, jump);
+                        cold_st(C_RNG, rng.d); cold_st(C_RNG + 1, rng.v0); cold_st(C_RNG + 2, rng.v1);
+                        cold_st(C_RNG + 3, rng.v2); cold_st(C_RNG + 4, rng.v3); cold_st(C_RNG + 5, rng.v4);
+                        cold_st(C_SAMPLE, 0u);
+                        L.pk = PK_NEW_PATH;
+                        state = S_PATH;
                     }                                   // else: item outside the image, fetch again
                 }
                 break;
             }
+        }
+        if (kCount) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+            switch (best) { case S_BOX: tally.cycles[0] += dt; break; case S_LEAF: tally.cycles[1] += dt; break; case S_XFORM: tally.cycles[2] += dt; break; case S_PATH: tally.cycles[3] += dt; break; default: tally.cycles[4] += dt; break; }
         }
     }
 
@@ -838,10 +899,12 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPart
     }
     if (kCount && !kPrimary) {
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
+        for (int k = 0; k < 5; k++) {
             const unsigned long long t = wave_sum(tally.turns[k]), l = wave_sum(tally.lanes[k]);
-            if ((threadIdx.x & 63u) == 0) { atomicAdd(&stats->sched_turns[k], t / 64); atomicAdd(&stats->sched_lanes[k], l); }
+            if ((threadIdx.x & 63u) == 0) { atomicAdd(&stats->sched_turns[k], t / 64); atomicAdd(&stats->sched_lanes[k], l); atomicAdd(&stats->sched_cycles[k], tally.cycles[k]); }
         }
+        for (int k = 0; k < 6; k++)
+            if ((threadIdx.x & 63u) == 0) atomicAdd(&stats->path_cycles[k], path_sections[(threadIdx.x >> 6) * 8 + k]);
     }
 }
 

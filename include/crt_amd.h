@@ -246,10 +246,13 @@ typedef struct crt_stats {
     uint64_t plane_tests;
     uint64_t texel_quads;      /* bilinear texture evaluations */
     /* scheduler detail of the trace kernel (counted build): how often each operation
-     * (0 box, 1 triangle, 2 enter, 3 exit, 4 shade, 5 camera, 6 fetch) was executed by a
+     * (0 box, 1 triangle, 2 transform, 3 path, 4 fetch) was executed by a
      * wave, and how many lanes took part in total */
     uint64_t sched_turns[8];
     uint64_t sched_lanes[8];
+    uint64_t sched_cycles[8];   /* shader clock cycles waves spent in turns of each operation */
+    uint64_t path_cycles[8];    /* cycles inside the path operation: lights, hit attributes, textures,
+                                   light sampling, BSDF sampling, next ray */
 } crt_stats;
 
 int crt_get_stats(crt_ctx* ctx, crt_stats* out);

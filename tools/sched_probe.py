@@ -12,8 +12,16 @@ print("counted kernel ms", ctx.last_kernel_ms())
 st = ctx.stats(); print(st)
 rays = st["closest_rays"] + st["shadow_rays"]
 tot = 0
-for k, (turns, lanes) in ctx.schedule_stats().items():
+sched = ctx.schedule_stats()
+cyc_total = sum(c for _, _, c in sched.values())
+for k, (turns, lanes, cyc) in sched.items():
     tot += turns
-    print(f"{k:9s} turns {turns:12d} lanes/turn {lanes / max(turns, 1):6.2f}  turns per 64 rays {turns * 64 / rays:8.2f}  lanes per ray {lanes / rays:8.2f}")
+    print(f"{k:9s} turns {turns:12d} lanes/turn {lanes / max(turns, 1):6.2f}  turns per 64 rays {turns * 64 / rays:8.2f}  lanes per ray {lanes / rays:6.2f}  cycles/turn {cyc / max(turns, 1):8.0f}  share {100 * cyc / max(cyc_total, 1):5.1f}%")
 print("total turns per 64 rays", tot * 64 / rays)
+raw = ctx.stats  # noqa
+import ctypes
+from cudaraytracing_amd import _capi as capi
+st2 = capi.Stats(); capi.lib().crt_get_stats(ctx._h, ctypes.byref(st2))
+pt = sched["path"][0]
+print("PATH sections cycles/turn: lights %.0f  attrs %.0f  textures %.0f  light-sample %.0f  bsdf %.0f  next-ray %.0f" % tuple(st2.path_cycles[k] / max(pt, 1) for k in range(6)))
 ctx.clear(); ctx.render_pass(0, spp); print("plain kernel ms", ctx.last_kernel_ms())
