@@ -146,7 +146,7 @@ def main():
         own_pixels = sum(1 for y in range(H) if (y // 16) % world == rank) * W
         nbytes, flops = algorithmic_work(c, own_pixels)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-        roofline = {"bound": "valu", "kernel": "render_kernel", "achieved": flops / (k_ms * 1e-3) * 1e-12, "peak": FP32_VECTOR_PEAK_TFLOPS,
+        roofline = {"bound": "valu", "kernel": "trace_kernel", "achieved": flops / (k_ms * 1e-3) * 1e-12, "peak": FP32_VECTOR_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": flops / (k_ms * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
                     "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(kernel_ms)),
                     "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt_amd.so")
+LIB_PATH = os.environ.get("CRT_AMD_LIBRARY") or os.path.join(_HERE, "libcrt_amd.so")   # override: kernel build variants under test
 
 OK, E_INVALID, E_IO, E_HIP, E_NOSCENE, E_LIMIT = 0, -1, -2, -3, -4, -5
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3

@@ -31,6 +31,9 @@
 namespace crt {
 
 #define CRT_BLOCK 256
+#ifndef CRT_WAVES_PER_SIMD
+#define CRT_WAVES_PER_SIMD 4        // register budget 128: the best measured balance of occupancy and spills
+#endif
 #define CRT_BIAS 0.02f
 #define CRT_MAX_SURVIVAL 0.95f
 #define CRT_F_EPS 1.1920929e-7f
@@ -288,7 +291,7 @@ DEV void acc_add(float* __restrict__ p, f3 v) {
 
 // ------------------------------------------------------------------ the scheduled path tracer
 template <bool kCount, bool kPrimary>
-__global__ __launch_bounds__(CRT_BLOCK, 4) void trace_kernel(DevScene S, DevPartition P, int samples,
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(DevScene S, DevPartition P, int samples,
                                                              const uint32_t* __restrict__ jump,
                                                              uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
                                                              int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
