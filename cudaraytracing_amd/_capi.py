@@ -89,6 +89,7 @@ _PROTOS = {
     "crt_scene_free": (None, [_VP]),
     "crt_scene_get_desc": (C.c_int, [_VP, C.POINTER(SceneDesc)]),
     "crt_scene_set_resolution": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    "crt_scene_make_instanced": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "crt_camera_derive": (C.c_int, [C.POINTER(Camera)]),
     "crt_host_last_error": (C.c_char_p, []),
     "crt_bvh_build": (C.c_int, [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,

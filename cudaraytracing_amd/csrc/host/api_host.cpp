@@ -105,6 +105,19 @@ int crt_scene_set_resolution(crt_scene* scene, uint32_t width, uint32_t height) 
     return CRT_OK;
 }
 
+int crt_scene_make_instanced(const crt_scene* source, uint32_t mesh_index, uint32_t copies, uint32_t seed,
+                             uint32_t width, uint32_t height, crt_scene** out) {
+    if (!source || !out) { crt::set_host_error("null argument"); return CRT_E_INVALID; }
+    crt_scene* sc = new (std::nothrow) crt_scene();
+    if (!sc) { crt::set_host_error("out of memory"); return CRT_E_INVALID; }
+    std::string err;
+    if (!crt::scene_make_instanced(source->s, mesh_index, copies, seed, width, height, sc->s, err)) {
+        delete sc; crt::set_host_error(err); return CRT_E_INVALID;
+    }
+    *out = sc;
+    return CRT_OK;
+}
+
 int crt_bvh_build(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
                   const float* mesh_box_min, const float* mesh_box_max, crt_bvh** out) {
     if ((!v && nv) || (!f && nf) || !mesh_box_min || !mesh_box_max || !out) { crt::set_host_error("null argument"); return CRT_E_INVALID; }

@@ -50,6 +50,12 @@ bool obj_load(const char* path, HostMesh& mesh, std::string& err);
 // --- scene loader (scene_load.cpp)
 bool scene_load_xml(const char* xml_path, const char* asset_root, HostScene& scene, std::string& err);
 void camera_derive(crt_camera& cam);
+mat34 mat_inverse(const mat34& m);           // Matrix::GetInverse operation order (math/matrix.cuh:25-56)
+void scene_compute_boxes(HostScene& scene);  // Node::CalculateBoundingBox over the flat node list
+
+// --- synthetic instanced scene (scene_synth.cpp)
+bool scene_make_instanced(const HostScene& source, uint32_t mesh_index, uint32_t copies, uint32_t seed,
+                          uint32_t width, uint32_t height, HostScene& out, std::string& err);
 
 // --- flat scene file (scene_file.cpp)
 bool scene_save_file(const HostScene& scene, const char* path, std::string& err);

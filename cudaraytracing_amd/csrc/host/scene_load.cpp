@@ -173,34 +173,6 @@ struct Loader {
         p[11] = l[2] * r[9] + l[5] * r[10] + l[8] * r[11] + l[11];
     }
 
-    // adjugate / determinant inverse with the operation order of Matrix::GetInverse
-    // (math/matrix.cuh:25-56)
-    static mat34 mat_inverse(const mat34& M) {
-        const float* c = M.c;
-        mat34 inv;
-        float* o = inv.c;
-        const float d_a = c[8] * c[10] - c[7] * c[11];
-        const float d_b = c[6] * c[11] - c[8] * c[9];
-        const float d_c = c[7] * c[9] - c[6] * c[10];
-        o[0] = c[4] * c[8] - c[5] * c[7];
-        o[1] = c[2] * c[7] - c[1] * c[8];
-        o[2] = c[1] * c[5] - c[2] * c[4];
-        o[3] = c[5] * c[6] - c[3] * c[8];
-        o[4] = c[0] * c[8] - c[2] * c[6];
-        o[5] = c[2] * c[3] - c[0] * c[5];
-        o[6] = c[3] * c[7] - c[4] * c[6];
-        o[7] = c[1] * c[6] - c[0] * c[7];
-        o[8] = c[0] * c[4] - c[1] * c[3];
-        o[9] = c[3] * d_a + c[4] * d_b + c[5] * d_c;
-        o[10] = c[0] * -d_a + c[1] * -d_b + c[2] * -d_c;
-        o[11] = c[0] * (c[5] * c[10] - c[4] * c[11]) + c[1] * (c[3] * c[11] - c[5] * c[9]) +
-                c[2] * (c[4] * c[9] - c[3] * c[10]);
-        const float det = c[0] * o[0] + c[1] * o[3] + c[2] * o[6];
-        const float s = 1.0f / det;
-        for (int i = 0; i < 12; i++) o[i] = o[i] * s;
-        return inv;
-    }
-
     // axis-angle rotation (Matrix::Rotation, math/matrix.cuh:138-164)
     static mat34 mat_rotation(f3 axis, float degrees) {
         mat34 m = mat_identity();
@@ -296,46 +268,6 @@ struct Loader {
         return true;
     }
 
-    struct Box { f3 lo, hi; };
-    static void box_init(Box& b) { b.lo = mk3(CRT_BIGFLOAT, CRT_BIGFLOAT, CRT_BIGFLOAT); b.hi = mk3(-CRT_BIGFLOAT, -CRT_BIGFLOAT, -CRT_BIGFLOAT); }
-    static void box_add(Box& b, f3 p) {
-        if (b.lo.x > p.x) b.lo.x = p.x; if (b.lo.y > p.y) b.lo.y = p.y; if (b.lo.z > p.z) b.lo.z = p.z;
-        if (b.hi.x < p.x) b.hi.x = p.x; if (b.hi.y < p.y) b.hi.y = p.y; if (b.hi.z < p.z) b.hi.z = p.z;
-    }
-
-    // Node::CalculateBoundingBox (scene/scene.cuh:191-251), run from the last node to the first
-    void compute_boxes() {
-        std::vector<Box> boxes(sc.nodes.size());
-        for (int i = (int)sc.nodes.size() - 1; i >= 0; i--) {
-            crt_node& n = sc.nodes[i];
-            Box b; box_init(b);
-            if (n.object_kind != CRT_OBJ_NONE) {
-                f3 lo, hi;
-                if (n.object_kind == CRT_OBJ_SPHERE) { lo = mk3(-1, -1, -1); hi = mk3(1, 1, 1); }
-                else if (n.object_kind == CRT_OBJ_PLANE) { lo = mk3(-1, -1, 0); hi = mk3(1, 1, 0); }
-                else {
-                    const HostMesh& m = sc.meshes[n.mesh_id];
-                    lo = mk3(m.box_min[0], m.box_min[1], m.box_min[2]);
-                    hi = mk3(m.box_max[0], m.box_max[1], m.box_max[2]);
-                }
-                Box t; box_init(t);
-                for (int k = 0; k < 8; k++) {
-                    const f3 corner = mk3((k & 4) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 1) ? hi.z : lo.z);
-                    box_add(t, xform_point(n.tm, corner));
-                }
-                box_add(b, t.lo); box_add(b, t.hi);
-            }
-            unsigned children = n.child_count, skip = 0;
-            for (unsigned j = (unsigned)i + 1; children > 0 && j < sc.nodes.size(); j++) {
-                if (skip > 0) { skip--; skip += sc.nodes[j].child_count; }
-                else { box_add(b, boxes[j].lo); box_add(b, boxes[j].hi); skip = sc.nodes[j].child_count; children--; }
-            }
-            boxes[i] = b;
-            n.box_min[0] = b.lo.x; n.box_min[1] = b.lo.y; n.box_min[2] = b.lo.z;
-            n.box_max[0] = b.hi.x; n.box_max[1] = b.hi.y; n.box_max[2] = b.hi.z;
-        }
-    }
-
     bool load_scene(const XmlElement& xscene) {
         // material 0 is the default: white diffuse / specular, black refraction / emission
         crt_material def{};
@@ -364,7 +296,7 @@ struct Loader {
                 sc.nodes[0].child_count++;
                 if (!assign_nodes(*c, ident)) return false;
             }
-        compute_boxes();
+        scene_compute_boxes(sc);
         sc.env_texture = make_texture(xscene.child("environment"), mk3(0, 0, 0));
         return true;
     }
@@ -396,6 +328,76 @@ struct Loader {
 };
 
 }  // namespace
+
+// adjugate / determinant inverse with the operation order of Matrix::GetInverse
+// (math/matrix.cuh:25-56)
+mat34 mat_inverse(const mat34& M) {
+    const float* c = M.c;
+    mat34 inv;
+    float* o = inv.c;
+    const float d_a = c[8] * c[10] - c[7] * c[11];
+    const float d_b = c[6] * c[11] - c[8] * c[9];
+    const float d_c = c[7] * c[9] - c[6] * c[10];
+    o[0] = c[4] * c[8] - c[5] * c[7];
+    o[1] = c[2] * c[7] - c[1] * c[8];
+    o[2] = c[1] * c[5] - c[2] * c[4];
+    o[3] = c[5] * c[6] - c[3] * c[8];
+    o[4] = c[0] * c[8] - c[2] * c[6];
+    o[5] = c[2] * c[3] - c[0] * c[5];
+    o[6] = c[3] * c[7] - c[4] * c[6];
+    o[7] = c[1] * c[6] - c[0] * c[7];
+    o[8] = c[0] * c[4] - c[1] * c[3];
+    o[9] = c[3] * d_a + c[4] * d_b + c[5] * d_c;
+    o[10] = c[0] * -d_a + c[1] * -d_b + c[2] * -d_c;
+    o[11] = c[0] * (c[5] * c[10] - c[4] * c[11]) + c[1] * (c[3] * c[11] - c[5] * c[9]) +
+            c[2] * (c[4] * c[9] - c[3] * c[10]);
+    const float det = c[0] * o[0] + c[1] * o[3] + c[2] * o[6];
+    const float s = 1.0f / det;
+    for (int i = 0; i < 12; i++) o[i] = o[i] * s;
+    return inv;
+}
+
+
+struct Box { f3 lo, hi; };
+static void box_init(Box& b) { b.lo = mk3(CRT_BIGFLOAT, CRT_BIGFLOAT, CRT_BIGFLOAT); b.hi = mk3(-CRT_BIGFLOAT, -CRT_BIGFLOAT, -CRT_BIGFLOAT); }
+static void box_add(Box& b, f3 p) {
+    if (b.lo.x > p.x) b.lo.x = p.x; if (b.lo.y > p.y) b.lo.y = p.y; if (b.lo.z > p.z) b.lo.z = p.z;
+    if (b.hi.x < p.x) b.hi.x = p.x; if (b.hi.y < p.y) b.hi.y = p.y; if (b.hi.z < p.z) b.hi.z = p.z;
+}
+
+// Node::CalculateBoundingBox (scene/scene.cuh:191-251), run from the last node to the first
+void scene_compute_boxes(HostScene& sc) {
+    std::vector<Box> boxes(sc.nodes.size());
+    for (int i = (int)sc.nodes.size() - 1; i >= 0; i--) {
+        crt_node& n = sc.nodes[i];
+        Box b; box_init(b);
+        if (n.object_kind != CRT_OBJ_NONE) {
+            f3 lo, hi;
+            if (n.object_kind == CRT_OBJ_SPHERE) { lo = mk3(-1, -1, -1); hi = mk3(1, 1, 1); }
+            else if (n.object_kind == CRT_OBJ_PLANE) { lo = mk3(-1, -1, 0); hi = mk3(1, 1, 0); }
+            else {
+                const HostMesh& m = sc.meshes[n.mesh_id];
+                lo = mk3(m.box_min[0], m.box_min[1], m.box_min[2]);
+                hi = mk3(m.box_max[0], m.box_max[1], m.box_max[2]);
+            }
+            Box t; box_init(t);
+            for (int k = 0; k < 8; k++) {
+                const f3 corner = mk3((k & 4) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 1) ? hi.z : lo.z);
+                box_add(t, xform_point(n.tm, corner));
+            }
+            box_add(b, t.lo); box_add(b, t.hi);
+        }
+        unsigned children = n.child_count, skip = 0;
+        for (unsigned j = (unsigned)i + 1; children > 0 && j < sc.nodes.size(); j++) {
+            if (skip > 0) { skip--; skip += sc.nodes[j].child_count; }
+            else { box_add(b, boxes[j].lo); box_add(b, boxes[j].hi); skip = sc.nodes[j].child_count; children--; }
+        }
+        boxes[i] = b;
+        n.box_min[0] = b.lo.x; n.box_min[1] = b.lo.y; n.box_min[2] = b.lo.z;
+        n.box_max[0] = b.hi.x; n.box_max[1] = b.hi.y; n.box_max[2] = b.hi.z;
+    }
+}
+
 
 // RenderInfo::Load (lib/xmlload.cu:324-354)
 void camera_derive(crt_camera& cam) {

@@ -29,6 +29,13 @@ class Scene:
     def load(cls, path, asset_root=None):
         return cls.load_file(path) if str(path).endswith(".crtscene") else cls.load_xml(path, asset_root)
 
+    def make_instanced(self, mesh_index, copies, seed=1, width=3840, height=2160):
+        """Synthetic stress scene: `copies` jittered copies of one mesh of this scene flattened into one mesh."""
+        h = C.c_void_p()
+        capi.check_host(capi.lib().crt_scene_make_instanced(self._h, int(mesh_index), int(copies), int(seed),
+                                                            int(width), int(height), C.byref(h)))
+        return Scene(h.value)
+
     def save_file(self, path):
         capi.check_host(capi.lib().crt_scene_save_file(self._h, str(path).encode()))
 

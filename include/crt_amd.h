@@ -130,6 +130,16 @@ int crt_scene_get_desc(const crt_scene* scene, crt_scene_desc* out);
  * RenderInfo::Load does (lib/xmlload.cu:324-354). */
 int crt_scene_set_resolution(crt_scene* scene, uint32_t width, uint32_t height);
 
+/* Synthetic stress scene: `copies` scaled, z-rotated copies of mesh
+ * `mesh_index` of `source` on a jittered 3-D grid, flattened into ONE mesh (one
+ * BVH), over a plane floor with one point light; the placement is a fixed
+ * function of `seed` (see csrc/host/scene_synth.cpp).  The reference ships no
+ * such scene; 1582 copies of its 6320-triangle teapot give the ten-million-
+ * triangle workload that no cache holds.  The BVH over the result is built by
+ * the same deterministic builder as any other mesh (renderer/bvh.cu:7-35). */
+int crt_scene_make_instanced(const crt_scene* source, uint32_t mesh_index, uint32_t copies, uint32_t seed,
+                             uint32_t width, uint32_t height, crt_scene** out);
+
 /* Recompute the derived camera fields of `cam` from position/target/up/fov/
  * width/height (same arithmetic as crt_scene_set_resolution). */
 int crt_camera_derive(crt_camera* cam);

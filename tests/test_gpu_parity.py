@@ -129,6 +129,30 @@ def test_render_is_bit_exact(gpu_ctx, name, w, h, spp):
     assert np.array_equal(gpu_ctx.read_image(), orc.convert(ref[0], o.srgb, 1.0))
 
 
+def test_instanced_scene_is_bit_exact(gpu_ctx, tmp_path):
+    """BASELINE config 5 at reduced size: copies of teapot.obj flattened into one mesh (126 k triangles,
+    BVH depth 22, so the traversal stack in LDS is deeper than on any shipped scene), floor, point light."""
+    src = crt.Scene.load_file(scene_path("proj5_box"))
+    syn = src.make_instanced(0, 20, seed=1, width=192, height=108)
+    path = str(tmp_path / "instanced20.crtscene")
+    syn.save_file(path)
+    o = orc.OracleScene(path)
+    assert o.bvh(0)["depth"] > 17
+    gpu_ctx.upload(syn)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, 3)
+    acc = gpu_ctx.read_accumulators()
+    ref, cnt = o.render(0, 3, count=True)
+    for k, n in enumerate(("results", "normals", "albedos")):
+        assert same(acc[k], ref[k]), n
+    st = gpu_ctx.stats()
+    assert (st["closest_rays"], st["shadow_rays"]) == (cnt["closest_rays"], cnt["shadow_rays"])
+    ids = gpu_ctx.primary_hits(0)
+    oid = o.primary_hits(0)
+    for a, b in zip(ids, oid):
+        assert same(a, b)
+
+
 def test_counted_kernel_matches_oracle_counters(gpu_ctx):
     s, o = load_both("final_frame0042", 192, 108)
     gpu_ctx.upload(s)

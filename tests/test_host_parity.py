@@ -183,3 +183,45 @@ def test_png_round_trip(tmp_path):
         L.crt_free(p)
         assert np.array_equal(got, np.asarray(src.convert("RGB"))), mode
     assert L.crt_png_read_rgb8(b"/nonexistent.png", ctypes.byref(p), ctypes.byref(w), ctypes.byref(h)) == capi.E_IO
+
+
+def test_instanced_scene_generator(tmp_path):
+    """The synthetic instanced scene (BASELINE config 5 at reduced size) is a fixed function of its arguments,
+    survives the flat-file round trip, and its BVH (deeper than any shipped mesh) equals the oracle's."""
+    import hashlib
+    src = crt.Scene.load_file(scene_path("proj5_box"))
+    syn = src.make_instanced(0, 20, seed=1, width=320, height=180)
+    d = syn.desc()
+    assert (d.node_count, d.mesh_count, d.light_count, d.material_count) == (3, 1, 1, 3)
+    v, f, lo, hi = syn.mesh_arrays(0)
+    assert f.size == 3 * 20 * 6320 and v.size == 3 * 20 * 3241
+    assert np.array_equal(np.asarray(lo), v.reshape(-1, 3).min(0)) and np.array_equal(np.asarray(hi), v.reshape(-1, 3).max(0))
+    again = src.make_instanced(0, 20, seed=1, width=320, height=180).mesh_arrays(0)[0]
+    other = src.make_instanced(0, 20, seed=2, width=320, height=180).mesh_arrays(0)[0]
+    assert np.array_equal(v, again) and not np.array_equal(v, other)
+    assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16] == INSTANCED20_VERTEX_SHA
+    # copies keep their shape: every triangle of copy k is a similarity image of the source triangle
+    sv, sf, _, _ = src.mesh_arrays(0)
+    e_src = np.linalg.norm(sv.reshape(-1, 3)[sf.reshape(-1, 3)[:, 1]] - sv.reshape(-1, 3)[sf.reshape(-1, 3)[:, 0]], axis=1)
+    k = 7
+    fk = f.reshape(-1, 3)[k * 6320:(k + 1) * 6320]
+    e_k = np.linalg.norm(v.reshape(-1, 3)[fk[:, 1]] - v.reshape(-1, 3)[fk[:, 0]], axis=1)
+    ratio = e_k[e_src > 0] / e_src[e_src > 0]
+    assert 0.5 <= ratio.min() and ratio.max() <= 1.0 and ratio.max() - ratio.min() < 1e-4
+
+    path = str(tmp_path / "instanced20.crtscene")
+    syn.save_file(path)
+    o = orc.OracleScene(path)
+    mine = crt.build_bvh(v, f, lo, hi)
+    ref = o.bvh(0)
+    assert mine["depth"] == ref["depth"] > 17 and mine["node_count"] == ref["node_count"]
+    for key in ("leaf", "start", "count", "left", "right", "next", "elements"):
+        assert np.array_equal(mine[key].astype(np.int64), ref[key].astype(np.int64)), key
+    assert np.array_equal(mine["box"], ref["box"])
+    with pytest.raises(crt.CrtError):
+        src.make_instanced(5, 20)                      # no such mesh
+    with pytest.raises(crt.CrtError):
+        src.make_instanced(0, 1 << 20)                 # more triangles than a leaf reference can address
+
+
+INSTANCED20_VERTEX_SHA = "b4389332649debbf"      # generated by this build; pins the generator against silent changes
