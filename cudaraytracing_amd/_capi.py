@@ -108,6 +108,8 @@ _PROTOS = {
     "crt_clear_async": (C.c_int, [_VP, _VP]),
     "crt_render_pass": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int]),
     "crt_convert": (C.c_int, [_VP, C.c_float, C.c_int, _VP, _VP, C.c_int]),
+    "crt_prepare_denoise": (C.c_int, [_VP, C.c_float, _VP, _VP, _VP, _VP, C.c_int]),
+    "crt_convert_floats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int]),
     "crt_read_image": (C.c_int, [_VP, _VP]),
     "crt_read_accumulators": (C.c_int, [_VP, _VP, _VP, _VP]),
     "crt_device_buffers": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),

@@ -542,6 +542,32 @@ int crt_convert(crt_ctx* ctx, float pass_mul, int srgb, void* rgb_out_device, vo
     return CRT_OK;
 }
 
+int crt_prepare_denoise(crt_ctx* ctx, float pass_mul, float* beauty_device, float* normal_device, float* albedo_device,
+                        void* stream, int async) {
+    if (!ctx || !beauty_device || !normal_device || !albedo_device) return ctx ? fail(ctx, CRT_E_INVALID, "null output buffer") : CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n3 = ctx->S.width * ctx->S.height * 3;
+    hipLaunchKernelGGL(prepare_denoise_kernel, dim3((n3 + CRT_BLOCK - 1) / CRT_BLOCK), dim3(CRT_BLOCK), 0, (hipStream_t)stream,
+                       ctx->S.results, ctx->S.normals, ctx->S.albedos, beauty_device, normal_device, albedo_device, n3, pass_mul);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!async) HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return CRT_OK;
+}
+
+int crt_convert_floats(crt_ctx* ctx, const float* rgb_in_device, int srgb, void* rgb_out_device, void* stream, int async) {
+    if (!ctx || !rgb_in_device) return ctx ? fail(ctx, CRT_E_INVALID, "null input buffer") : CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->S.width * ctx->S.height;
+    uint8_t* out = rgb_out_device ? (uint8_t*)rgb_out_device : ctx->rgb8;
+    hipLaunchKernelGGL(convert_floats_kernel, dim3((n + CRT_BLOCK - 1) / CRT_BLOCK), dim3(CRT_BLOCK), 0, (hipStream_t)stream,
+                       rgb_in_device, out, n, srgb);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!async) HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return CRT_OK;
+}
+
 int crt_read_image(crt_ctx* ctx, uint8_t* rgb_host) {
     if (!ctx || !rgb_host) return CRT_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");

@@ -929,6 +929,31 @@ __global__ __launch_bounds__(CRT_BLOCK) void convert_kernel(const float* __restr
     out[3ull * i + 2] = clamp_to_byte(c.z * 256);
 }
 
+// PrepareForDenoise (math/color.cu:32-51): the three accumulators scaled by 1 / passes into the float3
+// images a denoiser takes (beauty, normal, albedo).
+__global__ __launch_bounds__(CRT_BLOCK) void prepare_denoise_kernel(const float* __restrict__ results, const float* __restrict__ normals,
+                                                                    const float* __restrict__ albedos, float* __restrict__ beauty,
+                                                                    float* __restrict__ normal, float* __restrict__ albedo,
+                                                                    uint32_t n3, float pass_mul) {
+    const uint32_t i = blockIdx.x * CRT_BLOCK + threadIdx.x;      // one float per thread: the repack is element-wise
+    if (i >= n3) return;
+    beauty[i] = results[i] * pass_mul;
+    normal[i] = normals[i] * pass_mul;
+    albedo[i] = albedos[i] * pass_mul;
+}
+
+// ConvertColors, float overload (math/color.cu:25-30): a float3 image (a denoiser's output) to 8 bits.
+__global__ __launch_bounds__(CRT_BLOCK) void convert_floats_kernel(const float* __restrict__ in, uint8_t* __restrict__ out,
+                                                                   uint32_t n, int srgb) {
+    const uint32_t i = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    f3 c = ld3(in + 3ull * i);
+    if (srgb) c = mk3(linear_to_srgb(c.x), linear_to_srgb(c.y), linear_to_srgb(c.z));
+    out[3ull * i] = clamp_to_byte(c.x * 256);
+    out[3ull * i + 1] = clamp_to_byte(c.y * 256);
+    out[3ull * i + 2] = clamp_to_byte(c.z * 256);
+}
+
 // ------------------------------------------------------------------ self tests
 __global__ void rng_selftest_kernel(const uint32_t* __restrict__ seeds, const uint32_t* __restrict__ jump_index,
                                     const uint32_t* __restrict__ jumps, uint32_t n, uint32_t draws, uint32_t* __restrict__ out) {

@@ -45,6 +45,14 @@ class Context:
         self._check(capi.lib().crt_convert(self._h, float(pass_mul), int(srgb), C.c_void_p(out_device_ptr or 0),
                                            C.c_void_p(stream or 0), 0 if wait else 1))
 
+    def prepare_denoise(self, pass_mul, beauty_ptr, normal_ptr, albedo_ptr, stream=None, wait=True):
+        """Accumulators * pass_mul into three device buffers (width * height * 3 floats each) given by address."""
+        self._check(capi.lib().crt_prepare_denoise(self._h, float(pass_mul), beauty_ptr, normal_ptr, albedo_ptr, stream, 0 if wait else 1))
+
+    def convert_floats(self, rgb_in_ptr, srgb, out_device_ptr=None, stream=None, wait=True):
+        """A float3 device image (e.g. a denoiser's output) to the 8-bit image."""
+        self._check(capi.lib().crt_convert_floats(self._h, rgb_in_ptr, int(srgb), out_device_ptr, stream, 0 if wait else 1))
+
     def read_image(self):
         img = np.empty((self.height, self.width, 3), np.uint8)
         self._check(capi.lib().crt_read_image(self._h, capi.np_ptr(img)))

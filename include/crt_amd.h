@@ -220,6 +220,19 @@ int crt_render_pass(crt_ctx* ctx, int pass_id, int samples, void* stream, int as
 int crt_convert(crt_ctx* ctx, float pass_mul, int srgb, void* rgb_out_device, void* stream,
                 int async);
 
+/* Denoiser hand-off.  crt_prepare_denoise replaces PrepareForDenoise
+ * (math/color.cu:32-51, launched from renderer/renderer.cu:89-92): the three
+ * accumulators times pass_mul (= 1 / passes) into three caller-owned device
+ * buffers of width * height * 3 floats, the beauty / normal / albedo images a
+ * denoiser takes.  crt_convert_floats replaces the float overload of
+ * ConvertColors (math/color.cu:25-30, renderer/renderer.cu:146): a float3
+ * device image, e.g. the denoiser's output, to the 8-bit image (sRGB curve
+ * when srgb != 0), into rgb_out_device or the context's own image when NULL.
+ * The filter between the two is the caller's (the reference links OIDN). */
+int crt_prepare_denoise(crt_ctx* ctx, float pass_mul, float* beauty_device, float* normal_device, float* albedo_device,
+                        void* stream, int async);
+int crt_convert_floats(crt_ctx* ctx, const float* rgb_in_device, int srgb, void* rgb_out_device, void* stream, int async);
+
 /* Copy the context's converted image to host memory (renderer/renderer.cu:57). */
 int crt_read_image(crt_ctx* ctx, uint8_t* rgb_host);
 

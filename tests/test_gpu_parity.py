@@ -259,6 +259,35 @@ def test_full_size_frame_properties(gpu_ctx):
     assert gpu_ctx.stats() == st
 
 
+def test_denoise_hand_off(gpu_ctx):
+    """PrepareForDenoise and the float overload of ConvertColors (math/color.cu:25-51): element-wise float
+    products and the same 8-bit conversion, so both are compared exactly."""
+    import torch
+    s, o = load_both("final_frame0042", 160, 90)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    passes = 3
+    for p in range(passes):
+        gpu_ctx.render_pass(p, 2)
+    acc = gpu_ctx.read_accumulators()
+    mul = np.float32(1.0) / np.float32(passes)
+    bufs = [torch.empty((90, 160, 3), dtype=torch.float32, device="cuda") for _ in range(3)]
+    gpu_ctx.prepare_denoise(mul, *[b.data_ptr() for b in bufs])
+    for b, a in zip(bufs, acc):
+        assert same(b.cpu().numpy(), a * mul)
+    # a pass-through "denoiser": the beauty image straight into the float conversion
+    gpu_ctx.convert_floats(bufs[0].data_ptr(), s.srgb)
+    img = gpu_ctx.read_image()
+    assert np.array_equal(img, orc.convert(np.ascontiguousarray(acc[0] * mul), o.srgb, 1.0))
+    gpu_ctx.convert(mul, s.srgb)
+    assert np.array_equal(img, gpu_ctx.read_image())
+    out = torch.zeros((90, 160, 3), dtype=torch.uint8, device="cuda")
+    gpu_ctx.convert_floats(bufs[0].data_ptr(), 0, out_device_ptr=out.data_ptr())
+    assert np.array_equal(out.cpu().numpy(), orc.convert(np.ascontiguousarray(acc[0] * mul), 0, 1.0))
+    with pytest.raises(crt.CrtError):
+        gpu_ctx.prepare_denoise(mul, None, None, None)
+
+
 def test_errors_through_the_abi(gpu_ctx):
     import ctypes
     from cudaraytracing_amd import _capi as capi

@@ -225,3 +225,24 @@ def test_instanced_scene_generator(tmp_path):
 
 
 INSTANCED20_VERTEX_SHA = "b4389332649debbf"      # generated by this build; pins the generator against silent changes
+
+
+def test_parallel_bvh_build_equals_sequential(monkeypatch):
+    """Above 2^18 triangles the builder works on several threads; node numbering, boxes and element order must
+    not depend on the thread count (1 thread = the sequential pre-order pass)."""
+    src = crt.Scene.load_file(scene_path("proj5_box"))
+    v, f, lo, hi = src.make_instanced(0, 45, seed=3, width=64, height=36).mesh_arrays(0)
+    assert f.size // 3 > 1 << 18
+    built = []
+    for threads in ("1", "5", "16"):
+        monkeypatch.setenv("CRT_BUILD_THREADS", threads)
+        built.append(crt.build_bvh(v, f, lo, hi))
+    for other in built[1:]:
+        assert other["node_count"] == built[0]["node_count"] and other["depth"] == built[0]["depth"]
+        for key in ("leaf", "start", "count", "left", "right", "next", "elements", "box"):
+            assert np.array_equal(other[key], built[0][key]), key
+    # pre-order numbering: the left child follows its parent, next = first node after the subtree
+    b = built[0]
+    inner = np.flatnonzero(b["leaf"] == 0)
+    assert np.array_equal(b["left"][inner], inner + 1)
+    assert np.array_equal(b["next"][b["left"][inner]], b["right"][inner])
