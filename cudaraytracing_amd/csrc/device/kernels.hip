@@ -7,17 +7,21 @@
 // takes the next unowned pixel from a global queue with one wave-aggregated
 // atomic (ballot + mbcnt prefix), so lanes do not idle on short pixels.
 //
-// The work of a pixel is cut into small operations - slab-test one 64-byte
-// box-pair record (scene-node scan and BVH descent are the same operation),
-// test one triangle, enter a node, leave a mesh, shade, start a path, fetch a
-// pixel - and every lane carries the operation it needs next.  Each turn of
-// the main loop the wave votes (ballot + popcount) and executes only the
-// operation most lanes are waiting for, so a lane in a rare phase does not
-// make the other 63 walk through its code; closest-hit and shadow queries
-// share the box and triangle operations.  The order of operations of any one
-// pixel is exactly the reference's, only their interleaving across lanes is
-// scheduled.  The per-lane traversal stack lives in LDS, laid out
-// [entry][thread] so that any mix of stack depths is bank-conflict free.
+// The work of a pixel is cut into five operations - BOX: slab-test one 64-byte
+// box-pair record (scene-node scan and BVH descent are the same operation);
+// LEAF: test one triangle; XFORM: enter a scene node or leave a mesh; PATH:
+// everything between two ray queries (shading, light and BSDF sampling, a new
+// camera ray); FETCH: take a pixel from the queue - and every lane carries the
+// operation it needs next.  Each turn of the main loop the wave votes (ballot +
+// popcount) and executes one operation for the lanes that wait for it, so a
+// lane in a rare phase does not make the other 63 walk through its code;
+// closest-hit and shadow queries share BOX, LEAF and XFORM.  The order of
+// operations of any one pixel is exactly the reference's, only their
+// interleaving across lanes is scheduled.  Registers hold the traversal state
+// only; what a pixel needs just between two queries (random stream, throughput,
+// pending light sample, ...) lives in a field-major side buffer in global
+// memory.  The per-lane traversal stack lives in LDS, laid out [entry][thread]
+// so that any mix of stack depths is bank-conflict free.
 //
 // Arithmetic keeps the reference's operation order (see crt_vec.h); the file is
 // compiled with -ffp-contract=off and uses the pinned transcendentals of
