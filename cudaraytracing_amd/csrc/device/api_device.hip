@@ -26,6 +26,11 @@ struct crt_ctx {
     uint8_t* rgb8 = nullptr;
     uint32_t* queue = nullptr;
     uint32_t* cold = nullptr;                  // per-thread path state of the trace kernel
+    uint32_t* tile_cost = nullptr;             // ray queries per tile, measured by the pass in flight
+    uint32_t* tile_order = nullptr;            // tiles sorted by the previous pass's cost
+    uint32_t tile_capacity = 0;
+    bool order_valid = false;
+    bool no_balance = false;                   // CRT_NO_BALANCE=1: always hand tiles out in storage order
     DevStats* stats = nullptr;
     std::map<int, uint32_t*> jumps;            // pass -> 160 x 5 jump matrix on the device
     static constexpr int kRing = 256;
@@ -199,6 +204,9 @@ void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_r
     const uint32_t strips = (ctx->S.height + strip_rows - 1) / strip_rows;
     const uint32_t owned = strips > part ? (strips - part + parts - 1) / parts : 0;
     P.total_items = owned * P.items_per_strip;
+    P.tile_order = nullptr;
+    P.tile_cost = nullptr;
+    ctx->order_valid = false;                  // costs of another partition say nothing about this one
 }
 
 }  // namespace
@@ -395,6 +403,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);
     if (const char* e = getenv("CRT_SCHED_SPECIAL_MIN")) S.sched_special_min = (uint32_t)atoi(e);
     if (const char* e = getenv("CRT_SCHED_HEAVY_MIN")) S.sched_heavy_min = (uint32_t)atoi(e);
+    { const char* e = getenv("CRT_NO_BALANCE"); ctx->no_balance = e && atoi(e) != 0; }
     if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
         (rc = upload(ctx, meshes, &S.meshes)) || (rc = upload(ctx, materials, &S.materials)) ||
         (rc = upload(ctx, textures, &S.textures)) || (rc = upload(ctx, texels, &S.texels)) || (rc = upload(ctx, lights, &S.lights)))
@@ -428,6 +437,14 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         const size_t threads = (size_t)ctx->num_cus * per_cu * CRT_BLOCK;
         HIP_TRY(ctx, hipMalloc((void**)&ctx->cold, threads * C_WORDS * 4));
         ctx->allocs.push_back(ctx->cold);
+    }
+    {
+        // one entry per 8x8 tile of the image, with room for the ragged last strip of any strip height up to 512 rows
+        ctx->tile_capacity = ((S.width + 7) / 8) * ((S.height + 7) / 8 + 64);
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tile_cost, (size_t)ctx->tile_capacity * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tile_order, (size_t)ctx->tile_capacity * 4));
+        ctx->allocs.push_back(ctx->tile_cost);
+        ctx->allocs.push_back(ctx->tile_order);
     }
 
     ctx->have_scene = true;
@@ -480,15 +497,30 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     uint32_t grid = (uint32_t)(ctx->num_cus * per_cu);
     const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
     if (grid > need) grid = need;
+    // Load balance: this pass measures a cost per tile and the next one hands tiles out costliest first.
+    // (Passes of one context are expected on one stream, or ordered by the caller.)
+    const uint32_t tiles = ctx->P.total_items >> 6;
+    DevPartition P = ctx->P;
+    const bool balance = tiles <= ctx->tile_capacity && !ctx->no_balance;
+    if (balance) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tile_cost, 0, (size_t)tiles * 4, stream));
+        P.tile_cost = ctx->tile_cost;
+        P.tile_order = ctx->order_valid ? ctx->tile_order : nullptr;
+    }
     const int slot = (int)(ctx->launches % crt_ctx::kRing);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], stream));
     if (counted)
-        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
+        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
     else
-        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, ctx->P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
+        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], stream));
     ctx->launches++;
+    if (balance) {
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ctx->tile_cost, ctx->tile_order, tiles);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->order_valid = true;
+    }
     if (!async) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return CRT_OK;
 }

@@ -130,6 +130,12 @@ struct DevPartition {
     uint32_t tiles_x;            // ceil(width / 8)
     uint32_t items_per_strip;    // tiles_x * (strip_rows / 8) * 64
     uint32_t total_items;        // owned strips * items_per_strip
+    // Tiles are handed out in the order of this table (costliest first, as measured by the previous
+    // pass) when it is set, in storage order otherwise; every pass adds the ray queries of each
+    // finished pixel to its tile's entry of tile_cost.  Pixels are independent, so the order of the
+    // queue does not change any result.
+    const uint32_t* tile_order;
+    uint32_t* tile_cost;
 };
 
 struct DevStats {

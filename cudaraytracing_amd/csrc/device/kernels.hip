@@ -220,12 +220,16 @@ DEV void camera_ray(const DevScene& S, uint32_t pX, uint32_t pY, Rng& rng, f3& p
     dir = end - start;
 }
 
-// queue item -> pixel; false when the item falls outside the image
-DEV bool item_to_pixel(const DevScene& S, const DevPartition& P, uint32_t item, uint32_t& pX, uint32_t& pY) {
-    const uint32_t strip_local = item / P.items_per_strip;
-    const uint32_t in_strip = item - strip_local * P.items_per_strip;
-    const uint32_t tile = in_strip >> 6, lane = in_strip & 63u;
-    const uint32_t tile_row = tile / P.tiles_x, tile_col = tile - tile_row * P.tiles_x;
+// queue item -> pixel; false when the item falls outside the image.  tile is the tile's index in
+// storage order (strip-major over the strips this context owns).
+DEV bool item_to_pixel(const DevScene& S, const DevPartition& P, uint32_t item, uint32_t& pX, uint32_t& pY, uint32_t& tile) {
+    const uint32_t lane = item & 63u;
+    tile = item >> 6;
+    if (P.tile_order) tile = P.tile_order[tile];
+    const uint32_t tiles_per_strip = P.items_per_strip >> 6;
+    const uint32_t strip_local = tile / tiles_per_strip;
+    const uint32_t in_strip = tile - strip_local * tiles_per_strip;
+    const uint32_t tile_row = in_strip / P.tiles_x, tile_col = in_strip - tile_row * P.tiles_x;
     const uint32_t strip = strip_local * P.parts + P.part;
     pX = tile_col * 8u + (lane & 7u);
     pY = strip * P.strip_rows + tile_row * 8u + (lane >> 3);
@@ -286,7 +290,9 @@ enum : uint32_t {
     C_NDIR = 12,      // 3
     C_NEE = 15,       // 3
     C_SAMPLE = 18, C_SEGMENTS = 19, C_FLAGS = 20,
-    C_WORDS = 21
+    C_TILE = 21,      // storage-order index of the pixel's tile
+    C_COST = 22,      // ray queries of this pixel so far
+    C_WORDS = 23
 };
 
 DEV void acc_add(float* __restrict__ p, f3 v) {
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                                                              int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
                                                              float* __restrict__ out_t, uint32_t* __restrict__ cold) {
     extern __shared__ uint32_t lds[];
-    __shared__ unsigned long long sect_clock[4], path_sections[32];      // counted build only
+    __shared__ unsigned long long sect_clock[4], path_sections[32], wave_clock[8];      // counted build only
     if (kCount) { if (threadIdx.x < 32) path_sections[threadIdx.x] = 0; __syncthreads(); }
     uint32_t* __restrict__ stack_ref = lds;
     float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * CRT_BLOCK);
@@ -311,6 +317,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const uint32_t node_count = S.node_count;
 
     Tally tally = {};
+    // counted build: when the wave started / first found the queue dry (per wave, in LDS)
+    if (kCount && (threadIdx.x & 63u) == 0) { wave_clock[(threadIdx.x >> 6) * 2] = __builtin_amdgcn_s_memtime(); wave_clock[(threadIdx.x >> 6) * 2 + 1] = 0; }
     const float F_PI = 3.14159265358979323846f;
     const float OVERPI = (float)(1.0f / 3.14159265358979323846);
     const float inv_samples = 1.0f / (float)samples;
@@ -520,6 +528,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         f3 contrib = cold_ld3(C_CONTRIB);
         int sample = (int)cold_ld(C_SAMPLE);
         uint32_t segments = cold_ld(C_SEGMENTS);
+        uint32_t cost = cold_ld(C_COST);
         f3 next_dir = mk3(0, 0, 1);
 
         if (L.pk == PK_SHADOW_CLEAR || L.pk == PK_SHADOW_BLOCKED) {
@@ -782,6 +791,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             } else if (L.pk != PK_NEW_PATH && ++sample >= samples) {
                 have_ray = false;
                 next_state = S_FETCH;
+                if (!kPrimary && P.tile_cost) atomicMax(P.tile_cost + cold_ld(C_TILE), cost);
             } else {
                 // a new path: camera ray (trace.cu:26-38)
                 const uint32_t pY = L.pI / S.width, pX = L.pI - pY * S.width;
@@ -806,6 +816,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         cold_st3(C_CONTRIB, contrib);
         cold_st(C_SAMPLE, (uint32_t)sample);
         cold_st(C_SEGMENTS, segments);
+        cold_st(C_COST, cost + 1);
         SECT(5);
         return next_state;
     };
@@ -833,8 +844,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const uint32_t n_fetch = (uint32_t)__popcll(__ballot(state == S_FETCH));
             const uint32_t special = n_leaf >= n_xf ? (uint32_t)S_LEAF : (uint32_t)S_XFORM;
             const uint32_t n_special = n_leaf >= n_xf ? n_leaf : n_xf;
-            const uint32_t heavy = n_path >= n_fetch ? (uint32_t)S_PATH : (uint32_t)S_FETCH;
-            const uint32_t n_heavy = n_path >= n_fetch ? n_path : n_fetch;
+            // a path turn starts by handing pixels to the lanes that wait for one, so both kinds count
+            const uint32_t heavy = S_PATH;
+            const uint32_t n_heavy = n_path + n_fetch;
             if (n_special >= S.sched_special_min) best = special;
             else if (n_box > 0 && n_box >= n_heavy) best = S_BOX;
             else if (n_heavy >= S.sched_heavy_min || (n_heavy > 0 && n_box == 0 && n_special == 0)) best = heavy;
@@ -849,33 +861,40 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             case S_BOX: if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; } if (state == S_BOX) state = op_box(); break;
             case S_LEAF: if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); break;
             case S_XFORM: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_XFORM; } if (state == S_XFORM) state = op_xform(); break;
-            case S_PATH: if (kCount) { tally.turns[3]++; tally.lanes[3] += state == S_PATH; } if (state == S_PATH) state = op_path(); break;
             default: {
                 // FETCH: idle lanes take consecutive items from the pixel queue with one atomic per wave
                 const bool need = state == S_FETCH;
-                if (kCount) { tally.turns[4]++; tally.lanes[4] += need; }
                 const unsigned long long mask = __ballot(need);
-                if (queue_empty) { if (need) state = S_DONE; break; }
-                uint32_t base = 0;
-                const uint32_t cnt = (uint32_t)__popcll(mask);
-                if (need && lane_rank(mask) == 0) base = atomicAdd(queue, cnt);
-                base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-                if (base + cnt >= P.total_items) queue_empty = true;       // uniform: the queue has run dry
-                if (need) {
-                    const uint32_t item = base + lane_rank(mask);
-                    uint32_t pX, pY;
-                    if (item >= P.total_items) state = S_DONE;
-                    else if (item_to_pixel(S, P, item, pX, pY)) {
-                        L.pI = pY * S.width + pX;
-                        Rng rng;
-                        rng_init(rng, L.pI, jump);
-                        cold_st(C_RNG, rng.d); cold_st(C_RNG + 1, rng.v0); cold_st(C_RNG + 2, rng.v1);
-                        cold_st(C_RNG + 3, rng.v2); cold_st(C_RNG + 4, rng.v3); cold_st(C_RNG + 5, rng.v4);
-                        cold_st(C_SAMPLE, 0u);
-                        L.pk = PK_NEW_PATH;
-                        state = S_PATH;
-                    }                                   // else: item outside the image, fetch again
+                if (mask != 0) {
+                    if (kCount) { tally.turns[4]++; tally.lanes[4] += need; }
+                    if (queue_empty) { if (need) state = S_DONE; }
+                    else {
+                        uint32_t base = 0;
+                        const uint32_t cnt = (uint32_t)__popcll(mask);
+                        if (need && lane_rank(mask) == 0) base = atomicAdd(queue, cnt);
+                        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+                        if (base + cnt >= P.total_items) { queue_empty = true; if (kCount && lane_rank(__ballot(true)) == 0 && wave_clock[(threadIdx.x >> 6) * 2 + 1] == 0) wave_clock[(threadIdx.x >> 6) * 2 + 1] = __builtin_amdgcn_s_memtime(); }      // uniform: the queue has run dry
+                        if (need) {
+                            const uint32_t item = base + lane_rank(mask);
+                            uint32_t pX, pY, tile;
+                            if (item >= P.total_items) state = S_DONE;
+                            else if (item_to_pixel(S, P, item, pX, pY, tile)) {
+                                L.pI = pY * S.width + pX;
+                                cold_st(C_TILE, tile); cold_st(C_COST, 0u);
+                                Rng rng;
+                                rng_init(rng, L.pI, jump);
+                                cold_st(C_RNG, rng.d); cold_st(C_RNG + 1, rng.v0); cold_st(C_RNG + 2, rng.v1);
+                                cold_st(C_RNG + 3, rng.v2); cold_st(C_RNG + 4, rng.v3); cold_st(C_RNG + 5, rng.v4);
+                                cold_st(C_SAMPLE, 0u);
+                                L.pk = PK_NEW_PATH;
+                                state = S_PATH;
+                            }                                   // else: item outside the image, fetch again
+                        }
+                    }
                 }
+                // PATH for every lane between two queries, the freshly fetched ones included
+                if (kCount) { tally.turns[3]++; tally.lanes[3] += state == S_PATH; tally.lanes[5] += state == S_DONE; tally.lanes[6] += state == S_FETCH; tally.lanes[7] += state == S_BOX; }
+                if (state == S_PATH) state = op_path();
                 break;
             }
         }
@@ -906,12 +925,18 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     }
     if (kCount && !kPrimary) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 8; k++) {
             const unsigned long long t = wave_sum(tally.turns[k]), l = wave_sum(tally.lanes[k]);
             if ((threadIdx.x & 63u) == 0) { atomicAdd(&stats->sched_turns[k], t / 64); atomicAdd(&stats->sched_lanes[k], l); atomicAdd(&stats->sched_cycles[k], tally.cycles[k]); }
         }
         for (int k = 0; k < 6; k++)
             if ((threadIdx.x & 63u) == 0) atomicAdd(&stats->path_cycles[k], path_sections[(threadIdx.x >> 6) * 8 + k]);
+        if ((threadIdx.x & 63u) == 0) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            const unsigned long long t_kernel = wave_clock[(threadIdx.x >> 6) * 2], t_dry = wave_clock[(threadIdx.x >> 6) * 2 + 1];
+            atomicAdd(&stats->path_cycles[6], t_end - t_kernel);                       // wave lifetime
+            atomicAdd(&stats->path_cycles[7], t_dry ? t_end - t_dry : 0ull);           // of which after the queue ran dry
+        }
     }
 }
 
@@ -931,6 +956,32 @@ __global__ __launch_bounds__(CRT_BLOCK) void convert_kernel(const float* __restr
     out[3ull * i] = clamp_to_byte(c.x * 256);
     out[3ull * i + 1] = clamp_to_byte(c.y * 256);
     out[3ull * i + 2] = clamp_to_byte(c.z * 256);
+}
+
+// Tile order for the next pass: tiles sorted by the cost the pass just finished measured, costliest
+// first, so that the lanes' last pixels are cheap ones and the persistent grid drains evenly.  One
+// block: counting sort over 2048 cost classes (order inside a class is arbitrary).
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
+    __shared__ uint32_t bins[2048];
+    __shared__ uint32_t max_cost;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) max_cost = 1;
+    bins[t] = 0; bins[t + 1024] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t i = t; i < n; i += 1024) m = cost[i] > m ? cost[i] : m;
+    atomicMax(&max_cost, m);
+    __syncthreads();
+    const unsigned long long top = max_cost;
+    for (uint32_t i = t; i < n; i += 1024) atomicAdd(&bins[2047u - (uint32_t)((unsigned long long)cost[i] * 2047ull / top)], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < 2048; b++) { const uint32_t c = bins[b]; bins[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024)
+        order[atomicAdd(&bins[2047u - (uint32_t)((unsigned long long)cost[i] * 2047ull / top)], 1u)] = i;
 }
 
 // PrepareForDenoise (math/color.cu:32-51): the three accumulators scaled by 1 / passes into the float3

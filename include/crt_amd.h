@@ -275,7 +275,8 @@ typedef struct crt_stats {
     uint64_t sched_lanes[8];
     uint64_t sched_cycles[8];   /* shader clock cycles waves spent in turns of each operation */
     uint64_t path_cycles[8];    /* cycles inside the path operation: lights, hit attributes, textures,
-                                   light sampling, BSDF sampling, next ray */
+                                   light sampling, BSDF sampling, next ray; [6] summed wave
+                                   lifetimes, [7] the part of them after the pixel queue ran dry */
 } crt_stats;
 
 int crt_get_stats(crt_ctx* ctx, crt_stats* out);

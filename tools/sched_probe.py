@@ -7,6 +7,7 @@ import cudaraytracing_amd as crt
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 s = crt.Scene.load_file(os.path.join(ROOT, "tests/golden/scenes/final_frame0042.crtscene")); s.set_resolution(1920, 1080)
 ctx = crt.Context(0); ctx.upload(s)
+ctx.render_pass(0, spp); ctx.clear()      # first pass measures the tile costs the counted pass is scheduled by
 ctx.render_pass_counted(0, spp)
 print("counted kernel ms", ctx.last_kernel_ms())
 st = ctx.stats(); print(st)
@@ -24,4 +25,6 @@ from cudaraytracing_amd import _capi as capi
 st2 = capi.Stats(); capi.lib().crt_get_stats(ctx._h, ctypes.byref(st2))
 pt = sched["path"][0]
 print("PATH sections cycles/turn: lights %.0f  attrs %.0f  textures %.0f  light-sample %.0f  bsdf %.0f  next-ray %.0f" % tuple(st2.path_cycles[k] / max(pt, 1) for k in range(6)))
+print("at path turns, lanes per turn: done %.1f  waiting to fetch %.1f  box %.1f" % tuple(st2.sched_lanes[k] / max(pt, 1) for k in (5, 6, 7)))
+print("wave lifetime after the queue ran dry: %.1f %%" % (100.0 * st2.path_cycles[7] / max(st2.path_cycles[6], 1)))
 ctx.clear(); ctx.render_pass(0, spp); print("plain kernel ms", ctx.last_kernel_ms())
