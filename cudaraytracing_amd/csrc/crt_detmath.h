@@ -19,7 +19,8 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
-#define CRT_HD __host__ __device__ inline
+// always inlined: the kernels are built without device function calls
+#define CRT_HD __host__ __device__ __attribute__((always_inline)) inline
 #else
 #define CRT_HD inline
 #endif

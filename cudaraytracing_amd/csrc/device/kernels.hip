@@ -403,14 +403,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         return after_scan();
     };
 
-    // ---- LEAF: one triangle of the pending leaf (IntersectTriangle / IntersectShadowTriangle,
-    // objects.cu:270-366)
-    auto op_leaf = [&]() -> uint32_t {
-        const uint32_t slot = leaf_start(L.pend), left = leaf_count(L.pend) - 1;
-        L.pend = make_leaf_ref(slot + 1, left);
+    // ---- LEAF: the next two triangles of the pending leaf, one after the other (IntersectTriangle /
+    // IntersectShadowTriangle, objects.cu:270-366); both records are fetched up front so that the
+    // pair costs one memory round trip
+    auto tri_test = [&](const float4 v0, const float4 v1, const float4 v2, uint32_t slot) -> bool {
         TALLY(tri_tests);
-        const float4* tp = reinterpret_cast<const float4*>(tris + slot);
-        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
         const f3 p0 = mk3(v0.x, v0.y, v0.z);
         const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
         const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
@@ -429,13 +426,26 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         ok = ok && !(t <= CRT_TRI_EPS || t >= far_limit);
         const float ndot = dot(cross(edge1, edge2), L.qdir);
         ok = ok && ((ndot < CRT_TRI_EPS) || (ndot > -CRT_TRI_EPS));
-        if (ok) {
-            if (L.shadow) return shadow_blocked();
+        if (ok && !L.shadow) {
             TALLY(tri_hits);
             L.hz = t;
             L.mesh_hit = true;
             L.h_kind = H_MESH; L.h_node = L.entered; L.h_a = b1; L.h_b = b2; L.h_c = slot; L.h_front = ndot < 0;
         }
+        return ok;
+    };
+    auto op_leaf = [&]() -> uint32_t {
+        const uint32_t slot = leaf_start(L.pend), count = leaf_count(L.pend);
+        const bool two = count >= 2;
+        const uint32_t second = two ? slot + 1 : slot;      // a single triangle is fetched twice rather than reading past the leaf
+        const uint32_t left = count - (two ? 2u : 1u);
+        L.pend = make_leaf_ref(slot + (two ? 2u : 1u), left);
+        const float4* tp = reinterpret_cast<const float4*>(tris + slot);
+        const float4* tq = reinterpret_cast<const float4*>(tris + second);
+        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+        const float4 b0 = tq[0], b1 = tq[1], b2 = tq[2];
+        if (tri_test(a0, a1, a2, slot) && L.shadow) return shadow_blocked();
+        if (two && tri_test(b0, b1, b2, second) && L.shadow) return shadow_blocked();
         if (left) return S_LEAF;
         return resolve(false, 0, 0);
     };
