@@ -278,6 +278,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
 
     std::vector<BoxPair> pairs(N);
     std::vector<TriRec> tris;
+    std::vector<TriAttr> attrs;
     std::vector<uint32_t> mesh_root(d->mesh_count, 0);
     auto node_half = [&](uint32_t i, float* bmin, float* bmax, uint32_t& ref) {
         if (i < N) {
@@ -307,6 +308,10 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
             memcpy(t.p2, M.v + 3 * M.f[3 * face + 2], 12);
             t.face = face;
             tris.push_back(t);
+            TriAttr a{};
+            if (M.nvn > 0) for (int k = 0; k < 3; k++) memcpy(a.n + 3 * k, M.vn + 3 * M.fn[3 * face + k], 12);
+            if (M.nvt > 0) for (int k = 0; k < 3; k++) memcpy(a.t + 3 * k, M.vt + 3 * M.ft[3 * face + k], 12);
+            attrs.push_back(a);
         }
         // interior nodes get consecutive records in node order
         const uint32_t nn = B.node_count();
@@ -337,25 +342,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         xf[i].mesh_id = n.object_kind == CRT_OBJ_MESH ? n.mesh_id : -1;
         xf[i].root_ref = n.object_kind == CRT_OBJ_MESH ? mesh_root[n.mesh_id] : 0;
         xf[i].material_id = n.material_id;
-        xf[i].pad = 0;
-    }
-
-    std::vector<DevMesh> meshes(d->mesh_count ? d->mesh_count : 1);
-    for (uint32_t m = 0; m < d->mesh_count; m++) {
-        const crt_mesh& M = d->meshes[m];
-        DevMesh dm{};
-        dm.has_normals = M.nvn > 0; dm.has_tex = M.nvt > 0;
-        if (dm.has_normals) {
-            std::vector<float> vn(M.vn, M.vn + 3ull * M.nvn);
-            std::vector<uint32_t> fn(M.fn, M.fn + 3ull * M.nf);
-            if ((rc = upload(ctx, vn, &dm.vn)) || (rc = upload(ctx, fn, &dm.fn))) return rc;
-        }
-        if (dm.has_tex) {
-            std::vector<float> vt(M.vt, M.vt + 3ull * M.nvt);
-            std::vector<uint32_t> ft(M.ft, M.ft + 3ull * M.nf);
-            if ((rc = upload(ctx, vt, &dm.vt)) || (rc = upload(ctx, ft, &dm.ft))) return rc;
-        }
-        meshes[m] = dm;
+        xf[i].flags = 0;
+        if (n.object_kind == CRT_OBJ_MESH) xf[i].flags = (d->meshes[n.mesh_id].nvn > 0 ? kXfHasNormals : 0u) | (d->meshes[n.mesh_id].nvt > 0 ? kXfHasTex : 0u);
     }
 
     std::vector<DevTexture> textures(d->texture_count);
@@ -405,7 +393,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     if (const char* e = getenv("CRT_SCHED_HEAVY_MIN")) S.sched_heavy_min = (uint32_t)atoi(e);
     { const char* e = getenv("CRT_NO_BALANCE"); ctx->no_balance = e && atoi(e) != 0; }
     if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
-        (rc = upload(ctx, meshes, &S.meshes)) || (rc = upload(ctx, materials, &S.materials)) ||
+        (rc = upload(ctx, attrs, &S.attrs)) || (rc = upload(ctx, materials, &S.materials)) ||
         (rc = upload(ctx, textures, &S.textures)) || (rc = upload(ctx, texels, &S.texels)) || (rc = upload(ctx, lights, &S.lights)))
         return rc;
 

@@ -52,6 +52,16 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec is three 16-byte loads");
 
+// Shading attributes of one triangle record (same index as its TriRec): the three vertex normals
+// and the three texture vertices, gathered at upload so that a shaded hit needs one fetch instead
+// of the mesh -> index triple -> vertex chain (MeshObject::IntersectTriangle, scene/objects.cu:308-320).
+struct alignas(16) TriAttr {
+    float n[9];
+    float t[9];
+    float pad[2];
+};
+static_assert(sizeof(TriAttr) == 80, "TriAttr is five 16-byte loads");
+
 // Per scene node, read only when a ray enters the node.
 struct alignas(16) NodeXf {
     float itm[12];      // world -> local
@@ -59,18 +69,10 @@ struct alignas(16) NodeXf {
     uint32_t root_ref;  // mesh: BVH root reference
     int32_t mesh_id;
     int32_t material_id;
-    uint32_t pad;
+    uint32_t flags;     // mesh: kXfHasNormals | kXfHasTex
 };
 static_assert(sizeof(NodeXf) == 112, "NodeXf layout");
-
-// Per mesh, read only when a closest hit on it is finalised.
-struct DevMesh {
-    const float* vn;        // normals, xyz
-    const uint32_t* fn;     // normal index triples per face
-    const float* vt;
-    const uint32_t* ft;
-    uint32_t has_normals, has_tex;
-};
+constexpr uint32_t kXfHasNormals = 1u, kXfHasTex = 2u;
 
 struct DevTexture {
     uint32_t width, height;
@@ -111,7 +113,7 @@ struct DevScene {
     const BoxPair* pairs;
     const TriRec* tris;
     const NodeXf* xf;
-    const DevMesh* meshes;
+    const TriAttr* attrs;
     const DevMaterial* materials;
     const DevTexture* textures;
     const uint8_t* texels;

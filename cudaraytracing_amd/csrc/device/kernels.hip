@@ -457,18 +457,23 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         const bool leaving = L.pend == kPendExit;
         const uint32_t idx = leaving ? L.entered : (L.pend & 0x1fffffffu);
         const uint32_t kind = L.pend >> 30;
-        const NodeXf* __restrict__ xf = S.xf + idx;
+        // the whole 112-byte record is fetched at once (both matrices and the tags) so that no second
+        // memory round trip follows the object test
+        const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
+        const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r3 = xp[3], r4 = xp[4], r5 = xp[5], r6 = xp[6];
+        const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
         if (leaving) {
-            if (L.mesh_hit) L.hpos = xform_point(xf->tm, L.qpos + L.hz * L.qdir);
+            if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos + L.hz * L.qdir);
             L.trav = false;
         } else {
             TALLY(node_enters);
-            L.qpos = xform_point(xf->itm, L.qpos);
-            L.qdir = xform_dir(xf->itm, L.qdir);
+            L.qpos = xform_point(itm, L.qpos);
+            L.qdir = xform_dir(itm, L.qdir);
             if (kind == CRT_OBJ_MESH) {
                 L.qinv = recip3(L.qdir);
                 L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
-                return resolve(true, xf->root_ref, 0.0f);
+                return resolve(true, __float_as_uint(r6.x), 0.0f);
             }
             const f3 pos = L.qpos, dir = L.qdir;
             bool got = false, front = true;
@@ -504,14 +509,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 if (L.shadow) return shadow_blocked();
                 const f3 p = pos + t * dir;
                 L.hz = t;
-                L.hpos = xform_point(xf->tm, p);
+                L.hpos = xform_point(tm, p);
                 L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
                 L.h_node = idx; L.h_front = front;
                 L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
             }
         }
-        L.qpos = xform_point(xf->tm, L.qpos);
-        L.qdir = xform_dir(xf->tm, L.qdir);
+        L.qpos = xform_point(tm, L.qpos);
+        L.qdir = xform_dir(tm, L.qdir);
         L.qinv = recip3(L.qdir);
         L.node = idx + 1;
         return after_scan();
@@ -604,25 +609,22 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 const NodeXf* __restrict__ xf = S.xf + L.h_node;
                 f3 n, uvw;
                 if (L.h_kind == H_MESH) {
-                    const float4* tp = reinterpret_cast<const float4*>(tris + L.h_c);
-                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                    const f3 p0 = mk3(v0.x, v0.y, v0.z);
-                    const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
-                    const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
-                    const uint32_t face = __float_as_uint(v0.w);
+                    // interpolated vertex normal and texture vertex of the hit triangle (objects.cu:308-320)
                     const float b1 = L.h_a, b2 = L.h_b;
                     const float b0 = 1 - b2 - b1;
-                    const DevMesh M = S.meshes[xf->mesh_id];
-                    if (!M.has_normals) n = normalized(cross(edge1, edge2));
-                    else {
-                        const uint32_t i0 = M.fn[3 * face], i1 = M.fn[3 * face + 1], i2 = M.fn[3 * face + 2];
-                        n = ld3(M.vn + 3 * i0) * b0 + ld3(M.vn + 3 * i1) * b1 + ld3(M.vn + 3 * i2) * b2;
+                    const float4* ap = reinterpret_cast<const float4*>(S.attrs + L.h_c);
+                    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+                    const uint32_t mesh_flags = xf->flags;
+                    if (!(mesh_flags & kXfHasNormals)) {
+                        const float4* tp = reinterpret_cast<const float4*>(tris + L.h_c);
+                        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                        const f3 p0 = mk3(v0.x, v0.y, v0.z);
+                        n = normalized(cross(mk3(v1.x, v1.y, v1.z) - p0, mk3(v2.x, v2.y, v2.z) - p0));
+                    } else {
+                        n = mk3(a0.x, a0.y, a0.z) * b0 + mk3(a0.w, a1.x, a1.y) * b1 + mk3(a1.z, a1.w, a2.x) * b2;
                     }
-                    if (!M.has_tex) uvw = mk3(0, 0, 0);
-                    else {
-                        const uint32_t i0 = M.ft[3 * face], i1 = M.ft[3 * face + 1], i2 = M.ft[3 * face + 2];
-                        uvw = ld3(M.vt + 3 * i0) * b0 + ld3(M.vt + 3 * i1) * b1 + ld3(M.vt + 3 * i2) * b2;
-                    }
+                    if (!(mesh_flags & kXfHasTex)) uvw = mk3(0, 0, 0);
+                    else uvw = mk3(a2.y, a2.z, a2.w) * b0 + mk3(a3.x, a3.y, a3.z) * b1 + mk3(a3.w, a4.x, a4.y) * b2;
                 } else {
                     const f3 p = mk3(L.h_a, L.h_b, __uint_as_float(L.h_c));
                     if (L.h_kind == H_SPHERE) {
