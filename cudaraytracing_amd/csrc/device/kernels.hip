@@ -375,12 +375,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         if (hitB) tB = dB;
         if (L.trav) {
             TALLY(bvh_interior);
-            if (!(hitA || hitB)) return resolve(false, 0, 0);
+            // both children go on the stack, far one first (objects.cu:216-218); when neither box is hit the
+            // slot above the top is written and left unused, so one copy of the pop loop serves both cases
+            const bool any = hitA || hitB;
             const bool a_near = tA <= tB;
             stack_ref[L.sp * CRT_BLOCK + tid] = a_near ? ref_b : ref_a;
             stack_t[L.sp * CRT_BLOCK + tid] = fmaxf(tA, tB);
-            L.sp++;
-            return resolve(true, a_near ? ref_a : ref_b, fminf(tA, tB));
+            L.sp += any ? 1u : 0u;
+            return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
         }
         // scan: node `node` is half A, node + 1 is half B.  Closest hit enters a node whose box is
         // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
