@@ -291,8 +291,9 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     };
     for (uint32_t i = 0; i < N; i++) {
         BoxPair& p = pairs[i];
-        node_half(i, p.a_min, p.a_max, p.ref_a);
-        node_half(i + 1, p.b_min, p.b_max, p.ref_b);
+        float lo[3], hi[3];
+        node_half(i, lo, hi, p.ref_a); set_box(p.a, lo, hi);
+        node_half(i + 1, lo, hi, p.ref_b); set_box(p.b, lo, hi);
         p.aux_a = p.aux_b = 0;
     }
     for (uint32_t m = 0; m < d->mesh_count; m++) {
@@ -326,8 +327,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
             if (B.leaf[i]) { if (B.elem_count[i] > 15) return fail(ctx, CRT_E_LIMIT, "BVH leaf with more than 15 elements"); continue; }
             BoxPair p{};
             const uint32_t l = B.left[i], r = B.right[i];
-            memcpy(p.a_min, &B.box[6 * l], 12); memcpy(p.a_max, &B.box[6 * l + 3], 12);
-            memcpy(p.b_min, &B.box[6 * r], 12); memcpy(p.b_max, &B.box[6 * r + 3], 12);
+            set_box(p.a, &B.box[6 * l], &B.box[6 * l + 3]);
+            set_box(p.b, &B.box[6 * r], &B.box[6 * r + 3]);
             p.ref_a = ref_of(l); p.ref_b = ref_of(r);
             pairs.push_back(p);
         }

@@ -4,7 +4,7 @@
 // arrays, so a lane's whole traversal state is a 32-bit record index:
 //
 //  * box-pair records (64 B, one cache line, fetched as 4 x dwordx4 per lane):
-//    two boxes and two 32-bit references.  Records [0, node_count) describe the
+//    two boxes (min / max interleaved per axis) and two 32-bit references.  Records [0, node_count) describe the
 //    scene's node list: record i holds the world boxes of node i and node i+1,
 //    so the linear node scan of the reference (renderer/trace.cu:51-68,
 //    166-193) advances two nodes per fetch.  The records after that are the
@@ -24,8 +24,8 @@
 namespace crt {
 
 struct alignas(16) BoxPair {
-    float a_min[3], a_max[3];
-    float b_min[3], b_max[3];
+    float a[6];                 // box A as (min, max) pairs per axis: x, y, z - the layout the packed
+    float b[6];                 // two-float vector instructions of the slab test read without a shuffle
     uint32_t ref_a, ref_b;
     uint32_t aux_a, aux_b;
 };
@@ -33,6 +33,11 @@ static_assert(sizeof(BoxPair) == 64, "BoxPair must be one 64-byte line");
 
 // BVH child reference.  Leaf: bit 31 set, bits 30..27 = triangle count (0..8),
 // bits 26..0 = first triangle record.  Interior: absolute box-pair record index.
+// host-side helper: fill one half of a pair from min / max triples
+inline void set_box(float* half, const float* bmin, const float* bmax) {
+    for (int k = 0; k < 3; k++) { half[2 * k] = bmin[k]; half[2 * k + 1] = bmax[k]; }
+}
+
 constexpr uint32_t kRefLeaf = 0x80000000u;
 constexpr uint32_t kRefNone = 0xffffffffu;     // only as "stack empty" marker
 CRT_HD uint32_t make_leaf_ref(uint32_t start, uint32_t count) { return kRefLeaf | (count << 27) | start; }

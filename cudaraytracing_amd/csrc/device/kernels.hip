@@ -106,16 +106,29 @@ struct Tally {
 DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
 // Box slab test (Box::IntersectRay / IntersectShadowRay, scene/rays.cuh:138-187) with the
-// reciprocal direction hoisted; dist is meaningful only when the test passes.
-DEV bool slab(const float* bmin, const float* bmax, f3 pos, f3 inv, float tmax, float& dist) {
-    const float lx = (bmin[0] - pos.x) * inv.x, ly = (bmin[1] - pos.y) * inv.y, lz = (bmin[2] - pos.z) * inv.z;
-    const float hx = (bmax[0] - pos.x) * inv.x, hy = (bmax[1] - pos.y) * inv.y, hz = (bmax[2] - pos.z) * inv.z;
-    const float cx = fminf(lx, hx), cy = fminf(ly, hy), cz = fminf(lz, hz);
-    const float fx = fmaxf(lx, hx), fy = fmaxf(ly, hy), fz = fmaxf(lz, hz);
+// reciprocal direction hoisted; dist is meaningful only when the test passes.  Each argument is the
+// (min, max) pair of one axis: subtraction and multiplication run as two-float packed instructions
+// (v_pk_add_f32 / v_pk_mul_f32), which round each half exactly like the scalar forms.
+typedef float f2 __attribute__((ext_vector_type(2)));
+DEV bool slab(f2 bx, f2 by, f2 bz, f3 pos, f3 inv, float tmax, float& dist) {
+    const f2 tx = (bx - pos.x) * inv.x, ty = (by - pos.y) * inv.y, tz = (bz - pos.z) * inv.z;
+    const float cx = fminf(tx.x, tx.y), cy = fminf(ty.x, ty.y), cz = fminf(tz.x, tz.y);
+    const float fx = fmaxf(tx.x, tx.y), fy = fmaxf(ty.x, ty.y), fz = fmaxf(tz.x, tz.y);
     const float tEnter = fmaxf(cx, fmaxf(cy, cz));
     const float tExit = fminf(fx, fminf(fy, fz));
     dist = tEnter >= -FLT_EPSILON ? tEnter : tExit;
     return (tEnter >= -FLT_EPSILON || tExit >= -FLT_EPSILON) && tEnter <= tExit && tEnter <= tmax;
+}
+
+// Node::ToLocal / FromLocal for a whole ray (scene/scene.cuh:150-189): x, y, z hold (position, direction) pairs;
+// both are multiplied by the 3x3 part with the operation order of xform_point / xform_dir, then the position
+// half gets the translation.
+DEV void xform_ray(const float* c, f2& x, f2& y, f2& z) {
+    f2 nx = c[0] * x + c[3] * y + c[6] * z;
+    f2 ny = c[1] * x + c[4] * y + c[7] * z;
+    f2 nz = c[2] * x + c[5] * y + c[8] * z;
+    nx.x = nx.x + c[9]; ny.x = ny.x + c[10]; nz.x = nz.x + c[11];
+    x = nx; y = ny; z = nz;
 }
 
 DEV f3 recip3(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
@@ -262,7 +275,14 @@ struct Lane {
     uint32_t pI;                    // pixel being rendered
     uint32_t pk;                    // why the lane is in PATH
     // current ray query (closest hit or shadow)
-    f3 qpos, qdir, qinv;            // ray in the space it is currently in, and 1/dir
+    // Ray in the space it is currently in, kept as (position, direction) pairs per axis so that transforms and
+    // the triangle test run on two-float packed instructions; and 1 / direction.
+    f2 pdx, pdy, pdz;
+    f3 qinv;
+    DEV f3 qpos() const { return mk3(pdx.x, pdy.x, pdz.x); }
+    DEV f3 qdir() const { return mk3(pdx.y, pdy.y, pdz.y); }
+    DEV void set_qpos(f3 p) { pdx.x = p.x; pdy.x = p.y; pdz.x = p.z; }
+    DEV void set_qdir(f3 d) { pdx.y = d.x; pdy.y = d.y; pdz.y = d.z; }
     float limit;                    // slab t_max: FLT_MAX for closest hit, the light distance for shadow rays
     uint32_t node;                  // next scene node to scan
     uint32_t cur;                   // BVH record to expand
@@ -364,13 +384,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         const uint32_t rec_idx = L.trav ? L.cur : L.node;
         const float4* rp = reinterpret_cast<const float4*>(pairs + rec_idx);
         const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-        const float a_min[3] = {q0.x, q0.y, q0.z}, a_max[3] = {q0.w, q1.x, q1.y};
-        const float b_min[3] = {q1.z, q1.w, q2.x}, b_max[3] = {q2.y, q2.z, q2.w};
         const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
         float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
         float dA, dB;
-        const bool hitA = slab(a_min, a_max, L.qpos, L.qinv, L.limit, dA);
-        const bool hitB = slab(b_min, b_max, L.qpos, L.qinv, L.limit, dB);
+        const bool hitA = slab(f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, L.qpos(), L.qinv, L.limit, dA);
+        const bool hitB = slab(f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, L.qpos(), L.qinv, L.limit, dB);
         if (hitA) tA = dA;
         if (hitB) tB = dB;
         if (L.trav) {
@@ -410,23 +428,31 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     // pair costs one memory round trip
     auto tri_test = [&](const float4 v0, const float4 v1, const float4 v2, uint32_t slot) -> bool {
         TALLY(tri_tests);
-        const f3 p0 = mk3(v0.x, v0.y, v0.z);
-        const f3 edge1 = mk3(v1.x, v1.y, v1.z) - p0;
-        const f3 edge2 = mk3(v2.x, v2.y, v2.z) - p0;
-        const f3 rXe2 = cross(L.qdir, edge2);
-        const float det = dot(edge1, rXe2);
+        // Same operations and order as the scalar form; independent products and sums of the two cross
+        // products and of the dot products are paired into packed instructions.
+        const f2 ex = f2{v1.x, v2.x} - v0.x, ey = f2{v1.y, v2.y} - v0.y, ez = f2{v1.z, v2.z} - v0.z;   // (edge1, edge2)
+        f2 odx = L.pdx, ody = L.pdy, odz = L.pdz;                                                        // (offset, dir)
+        odx.x -= v0.x; ody.x -= v0.y; odz.x -= v0.z;
+        // (oXe1, rXe2) = (cross(offset, edge1), cross(dir, edge2)), component-wise as in cross()
+        const f2 cx = ody * ez - ey * odz;
+        const f2 cy = -(odx * ez - ex * odz);
+        const f2 cz = odx * ey - ex * ody;
+        // (det, t numerator) = (dot(edge1, rXe2), dot(edge2, oXe1)); (b1, b2 numerators) = (dot(offset, rXe2), dot(dir, oXe1)):
+        // each pair multiplies by the cross products with their halves swapped
+        const f2 u = ex * cx.yx + ey * cy.yx + ez * cz.yx;
+        const f2 w = odx * cx.yx + ody * cy.yx + odz * cz.yx;
+        const f3 edge1 = mk3(ex.x, ey.x, ez.x), edge2 = mk3(ex.y, ey.y, ez.y), dir = mk3(odx.y, ody.y, odz.y);
+        const float det = u.x;
         bool ok = !(det > -CRT_TRI_EPS && det < CRT_TRI_EPS);
         const float idet = 1 / det;
-        const f3 offset = L.qpos - p0;
-        const float b1 = idet * dot(offset, rXe2);
+        const float b1 = idet * w.x;
         ok = ok && !(b1 <= CRT_TRI_EPS || b1 >= 1 + CRT_TRI_EPS);
-        const f3 oXe1 = cross(offset, edge1);
-        const float b2 = idet * dot(L.qdir, oXe1);
+        const float b2 = idet * w.y;
         ok = ok && !(b2 <= -CRT_TRI_EPS || (b1 + b2) >= 1 + CRT_TRI_EPS);
-        const float t = idet * dot(edge2, oXe1);
+        const float t = idet * u.y;
         const float far_limit = (L.shadow ? L.limit : L.hz) + CRT_TRI_EPS;
         ok = ok && !(t <= CRT_TRI_EPS || t >= far_limit);
-        const float ndot = dot(cross(edge1, edge2), L.qdir);
+        const float ndot = dot(cross(edge1, edge2), dir);
         ok = ok && ((ndot < CRT_TRI_EPS) || (ndot > -CRT_TRI_EPS));
         if (ok && !L.shadow) {
             TALLY(tri_hits);
@@ -466,18 +492,17 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
         const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
         if (leaving) {
-            if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos + L.hz * L.qdir);
+            if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
             L.trav = false;
         } else {
             TALLY(node_enters);
-            L.qpos = xform_point(itm, L.qpos);
-            L.qdir = xform_dir(itm, L.qdir);
+            xform_ray(itm, L.pdx, L.pdy, L.pdz);
             if (kind == CRT_OBJ_MESH) {
-                L.qinv = recip3(L.qdir);
+                L.qinv = recip3(L.qdir());
                 L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
                 return resolve(true, __float_as_uint(r6.x), 0.0f);
             }
-            const f3 pos = L.qpos, dir = L.qdir;
+            const f3 pos = L.qpos(), dir = L.qdir();
             bool got = false, front = true;
             float t = 0;
             if (kind == CRT_OBJ_SPHERE) {
@@ -517,9 +542,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
             }
         }
-        L.qpos = xform_point(tm, L.qpos);
-        L.qdir = xform_dir(tm, L.qdir);
-        L.qinv = recip3(L.qdir);
+        xform_ray(tm, L.pdx, L.pdy, L.pdz);
+        L.qinv = recip3(L.qdir());
         L.node = idx + 1;
         return after_scan();
     };
@@ -563,9 +587,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 if (Li.kind != CRT_LIGHT_POINT) continue;
                 // PointLight::Intersect (scene/lights.cu:36-89)
                 const f3 lp = ld3(Li.pos);
-                const f3 o = L.qpos - lp;
-                const float a = dot(L.qdir, L.qdir);
-                const float b = dot(2 * L.qdir, o);
+                const f3 o = L.qpos() - lp;
+                const float a = dot(L.qdir(), L.qdir());
+                const float b = dot(2 * L.qdir(), o);
                 const float c = dot(o, o) - Li.size * Li.size;
                 const float det = b * b - 4 * a * c;
                 if (det < 0) continue;
@@ -576,7 +600,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     if (tf >= L.hz) continue;
                     L.hz = tf;
                     light_n = normalized(o);
-                    L.hpos = L.qpos + tf * L.qdir;
+                    L.hpos = L.qpos() + tf * L.qdir();
                     hit_light = (int)i;
                     continue;
                 }
@@ -584,7 +608,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 if (tb >= L.hz) continue;
                 L.hz = tb;
                 light_n = normalized(L.hpos);      // the previous hit position, as the reference reads it (lights.cu:78)
-                L.hpos = L.qpos + tb * L.qdir;
+                L.hpos = L.qpos() + tb * L.qdir();
                 hit_light = (int)i;
             }
             const bool any = hit_light >= 0 || L.h_kind != H_NONE;
@@ -596,9 +620,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 else if (any) { id = (int32_t)L.h_node; if (L.h_kind == H_MESH) face = (int32_t)tris[L.h_c].face; }
                 out_node[L.pI] = id; out_face[L.pI] = face; out_t[L.pI] = L.hz;
             } else if (!any) {
-                const f3 env = tex_env<kCount>(S, L.qdir, tally);
+                const f3 env = tex_env<kCount>(S, L.qdir(), tally);
                 acc_add(acc_target, contrib * env);
-                acc_add(acc_normal, contrib * normalized(L.qdir));
+                acc_add(acc_normal, contrib * normalized(L.qdir()));
                 acc_add(acc_albedo, contrib * env);
             } else if (hit_light >= 0) {
                 const f3 rad = ld3(S.lights[hit_light].radiance);
@@ -794,14 +818,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         uint32_t next_state = S_BOX;
         if (want_shadow) {
             tally.shadow_rays++;
-            L.qpos = spos; L.qdir = sdir; L.qinv = recip3(sdir);
+            L.set_qpos(spos); L.set_qdir(sdir); L.qinv = recip3(sdir);
             L.limit = sdist;
             L.shadow = true; L.trav = false; L.node = 0;
         } else {
             bool have_ray = true;
             if (alive) {
-                L.qpos = L.hpos;
-                L.qdir = next_dir;
+                L.set_qpos(L.hpos);
+                L.set_qdir(next_dir);
             } else if (L.pk != PK_NEW_PATH && ++sample >= samples) {
                 have_ray = false;
                 next_state = S_FETCH;
@@ -809,16 +833,18 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             } else {
                 // a new path: camera ray (trace.cu:26-38)
                 const uint32_t pY = L.pI / S.width, pX = L.pI - pY * S.width;
-                camera_ray(S, pX, pY, rng, L.qpos, L.qdir);
+                f3 cam_pos, cam_dir;
+                camera_ray(S, pX, pY, rng, cam_pos, cam_dir);
+                L.set_qpos(cam_pos); L.set_qdir(cam_dir);
                 contrib = mk3(1, 1, 1) * inv_samples;
                 segments = 0;
                 TALLY(paths);
             }
             if (have_ray) {
                 // TraceThroughScene prologue (renderer/trace.cu:44-50)
-                cold_st3(C_V, -normalized(L.qdir));
-                L.qpos += L.qdir * CRT_BIAS;
-                L.qinv = recip3(L.qdir);
+                cold_st3(C_V, -normalized(L.qdir()));
+                L.set_qpos(L.qpos() + L.qdir() * CRT_BIAS);
+                L.qinv = recip3(L.qdir());
                 L.limit = CRT_BIGFLOAT;
                 L.shadow = false; L.trav = false; L.node = 0;
                 L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
