@@ -351,7 +351,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     std::vector<uint8_t> texels;
     for (uint32_t i = 0; i < d->texture_count; i++) {
         const crt_texture& t = d->textures[i];
-        textures[i].width = t.width; textures[i].height = t.height; textures[i].offset = (uint32_t)texels.size(); textures[i].pad = 0;
+        textures[i].width = t.width; textures[i].height = t.height; textures[i].offset = (uint32_t)texels.size();
+        textures[i].first = (t.width && t.height) ? ((uint32_t)t.rgb[0] | ((uint32_t)t.rgb[1] << 8) | ((uint32_t)t.rgb[2] << 16)) : 0u;
         const size_t bytes = (size_t)t.width * t.height * 3;
         if (texels.size() + bytes > 0xffffffffull) return fail(ctx, CRT_E_LIMIT, "more than 4 GiB of texels");
         if (bytes) texels.insert(texels.end(), t.rgb, t.rgb + bytes);

@@ -82,7 +82,7 @@ constexpr uint32_t kXfHasNormals = 1u, kXfHasTex = 2u;
 struct DevTexture {
     uint32_t width, height;
     uint32_t offset;        // byte offset of texel (0,0) in the texel pool
-    uint32_t pad;
+    uint32_t first;         // texel (0,0) as r | g << 8 | b << 16: all there is to a 1x1 texture
 };
 
 struct DevMaterial {

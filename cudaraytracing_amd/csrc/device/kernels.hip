@@ -164,11 +164,19 @@ DEV f3 tex_eval(const DevScene& S, int tex, f3 uvw, Tally& tally) {
     if ((uint32_t)iy >= h) iy -= (int)(((uint32_t)iy / h) * h);
     int iyp = iy + 1;
     if ((uint32_t)iyp >= h) iyp -= (int)h;
-    const uint8_t* base = S.texels + t.offset;
-    const f3 c00 = texel(base + 3u * ((uint32_t)iy * w + (uint32_t)ix));
-    const f3 c01 = texel(base + 3u * ((uint32_t)iy * w + (uint32_t)ixp));
-    const f3 c10 = texel(base + 3u * ((uint32_t)iyp * w + (uint32_t)ix));
-    const f3 c11 = texel(base + 3u * ((uint32_t)iyp * w + (uint32_t)ixp));
+    f3 c00, c01, c10, c11;
+    if (w * h == 1u) {
+        // a constant colour (what every colour attribute of a material becomes): its one texel travels in the
+        // descriptor; the four taps and their weights are still combined as for any texture
+        c00 = mk3((float)(t.first & 255u), (float)((t.first >> 8) & 255u), (float)((t.first >> 16) & 255u)) * (1.0f / 256.0f);
+        c01 = c00; c10 = c00; c11 = c00;
+    } else {
+        const uint8_t* base = S.texels + t.offset;
+        c00 = texel(base + 3u * ((uint32_t)iy * w + (uint32_t)ix));
+        c01 = texel(base + 3u * ((uint32_t)iy * w + (uint32_t)ixp));
+        c10 = texel(base + 3u * ((uint32_t)iyp * w + (uint32_t)ix));
+        c11 = texel(base + 3u * ((uint32_t)iyp * w + (uint32_t)ixp));
+    }
     return c00 * ((1 - fx) * (1 - fy)) + c01 * (fx * (1 - fy)) + c10 * ((1 - fx) * fy) + c11 * (fx * fy);
 }
 
