@@ -413,21 +413,21 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // scan: node `node` is half A, node + 1 is half B.  Closest hit enters a node whose box is
         // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
         // subtree of a node with an object whose box it misses (trace.cu:171-185).
+        // (The half after the last node of an odd list is a dummy without an object and with an empty box.)
         const uint32_t kind_a = node_ref_kind(ref_a), kind_b = node_ref_kind(ref_b);
+        const uint32_t after_a = node_ref_after(ref_a), after_b = node_ref_after(ref_b);
+        const bool sh = L.shadow;
         const bool obj_a = kind_a != CRT_OBJ_NONE, obj_b = kind_b != CRT_OBJ_NONE;
-        const bool pass_a = L.shadow ? hitA : (hitA && tA < L.hz);
-        const bool pass_b = L.shadow ? hitB : (hitB && tB < L.hz);
-        const bool enter_a = obj_a && pass_a;
-        const uint32_t next_a = (L.shadow && obj_a) ? node_ref_after(ref_a) : L.node + 1;
-        const bool look_b = !enter_a && next_a == L.node + 1 && L.node + 1 < node_count;
-        const bool enter_b = look_b && obj_b && pass_b;
-        const uint32_t next_b = (L.shadow && obj_b) ? node_ref_after(ref_b) : L.node + 2;
-        if (kCount) { tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b && obj_b) ? 1u : 0u); }
-        if (enter_a || enter_b) {
+        const bool enter_a = obj_a & hitA & (sh | (tA < L.hz));
+        const bool jump_a = sh & obj_a & (after_a != L.node + 1);            // shadow ray past a missed subtree
+        const bool look_b = !(enter_a | jump_a);
+        const bool enter_b = look_b & obj_b & hitB & (sh | (tB < L.hz));
+        if (kCount) { tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b & obj_b) ? 1u : 0u); }
+        if (enter_a | enter_b) {
             L.pend = enter_a ? (L.node | (kind_a << 30)) : ((L.node + 1) | (kind_b << 30));
             return S_XFORM;
         }
-        L.node = look_b ? next_b : next_a;
+        L.node = jump_a ? after_a : ((sh & obj_b) ? after_b : L.node + 2);
         return after_scan();
     };
 
