@@ -30,6 +30,8 @@ struct crt_ctx {
     uint32_t* tile_order = nullptr;            // tiles sorted by the previous pass's cost
     uint32_t tile_capacity = 0;
     bool order_valid = false;
+    bool deep = false;                         // BVH deeper than the LDS stack: kDeep kernels
+    uint32_t stack_overflow = 0;               // stack entries per thread kept in the side buffer
     bool no_balance = false;                   // CRT_NO_BALANCE=1: always hand tiles out in storage order
     DevStats* stats = nullptr;
     std::map<int, uint32_t*> jumps;            // pass -> 160 x 5 jump matrix on the device
@@ -207,6 +209,17 @@ void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_r
     P.tile_order = nullptr;
     P.tile_cost = nullptr;
     ctx->order_valid = false;                  // costs of another partition say nothing about this one
+}
+
+template <bool kCount, bool kPrimary>
+void launch_trace(crt_ctx* ctx, uint32_t grid, hipStream_t stream, const DevPartition& P, int samples, const uint32_t* jump,
+                  int32_t* out_node, int32_t* out_face, float* out_t) {
+    if (ctx->deep)
+        hipLaunchKernelGGL((trace_kernel<kCount, kPrimary, true>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
+                           ctx->queue, ctx->stats, out_node, out_face, out_t, ctx->cold);
+    else
+        hipLaunchKernelGGL((trace_kernel<kCount, kPrimary, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
+                           ctx->queue, ctx->stats, out_node, out_face, out_t, ctx->cold);
 }
 
 }  // namespace
@@ -388,7 +401,13 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cam_pos, cam.position, 12); S.dof = cam.dof; S.pixel_size = cam.pixel_size;
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
-    S.stack_entries = max_depth + 2;
+    // LDS holds at most kLdsStackEntries slots per lane (4 blocks of 256 threads stay resident); deeper trees use the
+    // kernel variant whose stack overflows into the side buffer
+    constexpr uint32_t kLdsStackEntries = 19;
+    const uint32_t stack_total = max_depth + 2;
+    ctx->deep = stack_total > kLdsStackEntries;
+    ctx->stack_overflow = ctx->deep ? stack_total - kLdsStackEntries : 0;
+    S.stack_entries = ctx->deep ? kLdsStackEntries : stack_total;
     S.sched_box_min = 16; S.sched_special_min = 6; S.sched_heavy_min = 1;      // measured optimum on the benchmark frame
     if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);
     if (const char* e = getenv("CRT_SCHED_SPECIAL_MIN")) S.sched_special_min = (uint32_t)atoi(e);
@@ -415,17 +434,25 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // two LDS arrays (node reference, entry distance) of stack_entries x 256 words
     ctx->lds_bytes = (size_t)S.stack_entries * CRT_BLOCK * 4 * 2;
     if (ctx->lds_bytes > 160 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, (trace_kernel<false, false>), CRT_BLOCK, ctx->lds_bytes));
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, (trace_kernel<true, false>), CRT_BLOCK, ctx->lds_bytes));
+    if (ctx->deep) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, (trace_kernel<false, false, true>), CRT_BLOCK, ctx->lds_bytes));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, (trace_kernel<true, false, true>), CRT_BLOCK, ctx->lds_bytes));
+    } else {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, (trace_kernel<false, false, false>), CRT_BLOCK, ctx->lds_bytes));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, (trace_kernel<true, false, false>), CRT_BLOCK, ctx->lds_bytes));
+    }
     if (ctx->blocks_per_cu < 1) ctx->blocks_per_cu = 1;
     if (ctx->blocks_per_cu_counted < 1) ctx->blocks_per_cu_counted = 1;
     {
         const int per_cu = ctx->blocks_per_cu > ctx->blocks_per_cu_counted ? ctx->blocks_per_cu : ctx->blocks_per_cu_counted;
         const size_t threads = (size_t)ctx->num_cus * per_cu * CRT_BLOCK;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->cold, threads * C_WORDS * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->cold, threads * (C_WORDS + 2ull * ctx->stack_overflow) * 4));
         ctx->allocs.push_back(ctx->cold);
     }
     {
@@ -500,9 +527,9 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     const int slot = (int)(ctx->launches % crt_ctx::kRing);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], stream));
     if (counted)
-        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
+        launch_trace<true, false>(ctx, grid, stream, P, samples, jump, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump, ctx->queue, ctx->stats, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, ctx->cold);
+        launch_trace<false, false>(ctx, grid, stream, P, samples, jump, nullptr, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], stream));
     ctx->launches++;
@@ -642,8 +669,7 @@ int crt_primary_hits(crt_ctx* ctx, int pass_id, int32_t* node, int32_t* face, fl
         uint32_t grid = (uint32_t)(ctx->num_cus * ctx->blocks_per_cu);
         const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
         if (grid > need) grid = need;
-        hipLaunchKernelGGL((trace_kernel<false, true>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, nullptr,
-                           ctx->S, ctx->P, 1, jump, ctx->queue, ctx->stats, d_node, d_face, d_t, ctx->cold);
+        launch_trace<false, true>(ctx, grid, nullptr, ctx->P, 1, jump, d_node, d_face, d_t);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipDeviceSynchronize());

@@ -328,7 +328,9 @@ DEV void acc_add(float* __restrict__ p, f3 v) {
 }
 
 // ------------------------------------------------------------------ the scheduled path tracer
-template <bool kCount, bool kPrimary>
+// kDeep: the BVH is deeper than the LDS stack; entries above S.stack_entries live in a per-thread overflow
+// area of the side buffer (rarely reached: a ray's stack is usually a fraction of the tree depth).
+template <bool kCount, bool kPrimary, bool kDeep>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(DevScene S, DevPartition P, int samples,
                                                              const uint32_t* __restrict__ jump,
                                                              uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     if (kCount) { if (threadIdx.x < 32) path_sections[threadIdx.x] = 0; __syncthreads(); }
     uint32_t* __restrict__ stack_ref = lds;
     float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * CRT_BLOCK);
+    const uint32_t lds_entries = S.stack_entries;
     const uint32_t tid = threadIdx.x;
     const BoxPair* __restrict__ pairs = S.pairs;
     const TriRec* __restrict__ tris = S.tris;
@@ -361,6 +364,16 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     auto cold_ld3 = [&](uint32_t f) -> f3 { return mk3(__uint_as_float(cold_ld(f)), __uint_as_float(cold_ld(f + 1)), __uint_as_float(cold_ld(f + 2))); };
     auto cold_st3 = [&](uint32_t f, f3 v) { cold_st(f, __float_as_uint(v.x)); cold_st(f + 1, __float_as_uint(v.y)); cold_st(f + 2, __float_as_uint(v.z)); };
 
+    // traversal stack: LDS, with the overflow area behind the path state in the side buffer for deep trees
+    auto stack_put = [&](uint32_t slot, uint32_t ref, float t) {
+        if (!kDeep || slot < lds_entries) { stack_ref[slot * CRT_BLOCK + tid] = ref; stack_t[slot * CRT_BLOCK + tid] = t; }
+        else { cold_st(C_WORDS + 2 * (slot - lds_entries), ref); cold_st(C_WORDS + 2 * (slot - lds_entries) + 1, __float_as_uint(t)); }
+    };
+    auto stack_get = [&](uint32_t slot, uint32_t& ref, float& t) {
+        if (!kDeep || slot < lds_entries) { ref = stack_ref[slot * CRT_BLOCK + tid]; t = stack_t[slot * CRT_BLOCK + tid]; }
+        else { ref = cold_ld(C_WORDS + 2 * (slot - lds_entries)); t = __uint_as_float(cold_ld(C_WORDS + 2 * (slot - lds_entries) + 1)); }
+    };
+
     // the query has run out of scene nodes
     auto query_done = [&]() -> uint32_t { L.pk = L.shadow ? PK_SHADOW_CLEAR : PK_CLOSEST_DONE; return S_PATH; };
     auto shadow_blocked = [&]() -> uint32_t { L.pk = PK_SHADOW_BLOCKED; return S_PATH; };
@@ -373,8 +386,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (!have_next) {
                 if (L.sp == 0) { L.pend = kPendExit; return S_XFORM; }
                 L.sp--;
-                next_ref = stack_ref[L.sp * CRT_BLOCK + tid];
-                next_t = stack_t[L.sp * CRT_BLOCK + tid];
+                stack_get(L.sp, next_ref, next_t);
             }
             have_next = false;
             if (!L.shadow && L.hz < next_t) continue;
@@ -405,8 +417,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // slot above the top is written and left unused, so one copy of the pop loop serves both cases
             const bool any = hitA || hitB;
             const bool a_near = tA <= tB;
-            stack_ref[L.sp * CRT_BLOCK + tid] = a_near ? ref_b : ref_a;
-            stack_t[L.sp * CRT_BLOCK + tid] = fmaxf(tA, tB);
+            stack_put(L.sp, a_near ? ref_b : ref_a, fmaxf(tA, tB));
             L.sp += any ? 1u : 0u;
             return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
         }
