@@ -110,6 +110,9 @@ CASES = [
     ("proj13_box", 320, 180, 4),
     ("final_frame0001", 256, 144, 2),
     ("final_frame0042", 320, 180, 4),      # BASELINE config 4 scene: 20 meshes, dof, sRGB
+    ("proj5_plane", 320, 180, 4),
+    ("proj1_snowman", 320, 180, 2),        # no lights at all: no light sample is taken
+    ("proj7_checkerboard", 1280, 720, 16), # BASELINE config 3 at its full size
 ]
 
 
