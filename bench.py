@@ -33,6 +33,11 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X fp32 vector peak (FMA counted as 2
 HBM_PEAK_GBS = 8000.0
 
 
+# Image strips of this many rows go round-robin to the ranks: on the benchmark frame 8-row strips (one tile row)
+# leave the busiest of 8 ranks 0.8 % above the mean, 16-row strips 4 %.
+STRIP_ROWS = 8
+
+
 def algorithmic_work(c, pixels):
     """Bytes and flops one launch needs by the counting rule of the design notes: 24 B per scene-node
     box, 112 B per entered node (two transforms + tags), 56 B per expanded BVH interior node (two child
@@ -102,11 +107,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    # Rehearsal of the multi-rank path on a box with one GPU (CRT_BENCH_REHEARSAL=1): every rank renders on device 0
+    # and the collectives run over gloo on host copies.  Its timings mean nothing; it exists to exercise the code.
+    rehearsal = os.environ.get("CRT_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    coll_device = torch.device("cpu") if rehearsal else device
 
     scene_file = os.path.join(ROOT, "tests", "golden", "scenes", args.scene + ".crtscene")
     scene = crt.Scene.load_file(scene_file)
@@ -115,7 +129,7 @@ def main():
     ctx = crt.Context(local_rank)
     ctx.upload(scene)                      # BVH build + re-layout + H2D, outside the timed region
     upload_ms = (time.perf_counter() - t0) * 1e3
-    ctx.set_partition(rank, world, 16)
+    ctx.set_partition(rank, world, STRIP_ROWS)
     H, W = args.height, args.width
     rgb_dev = torch.zeros((H, W, 3), dtype=torch.uint8, device=device)
     rgb_host = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
@@ -126,7 +140,7 @@ def main():
         ctx.clear(stream=stream, wait=False)
         ctx.render_pass(0, args.spp, stream=stream, wait=False)
         ctx.convert(1.0, srgb, out_device_ptr=rgb_dev.data_ptr(), stream=stream, wait=False)
-        full = gather_rows(rgb_dev, rank, world, 16)
+        full = gather_rows(rgb_dev.cpu() if rehearsal else rgb_dev, rank, world, STRIP_ROWS)
         if rank == 0:
             rgb_host.copy_(full, non_blocking=True)
 
@@ -148,8 +162,8 @@ def main():
     kernel_ms = ctx.kernel_times()
 
     st = ctx.stats()                        # counters of the last frame (cleared at each frame start)
-    rays = torch.tensor([st["closest_rays"] + st["shadow_rays"], st["closest_rays"], st["shadow_rays"]], dtype=torch.float64, device=device)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    rays = torch.tensor([st["closest_rays"] + st["shadow_rays"], st["closest_rays"], st["shadow_rays"]], dtype=torch.float64, device=coll_device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,7 +178,7 @@ def main():
         ctx.render_pass_counted(0, args.spp)
         c = ctx.stats()
         ctx.kernel_times()
-        own_pixels = sum(1 for y in range(H) if (y // 16) % world == rank) * W
+        own_pixels = sum(1 for y in range(H) if (y // STRIP_ROWS) % world == rank) * W
         nbytes, flops = algorithmic_work(c, own_pixels)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         traffic, traffic_note = profiled_traffic(args)
@@ -176,6 +190,18 @@ def main():
                             "frac": nbytes / (k_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS},
                     "note": "no MFMA on this path (not a dense contraction); scene working set is cache resident, so the binding "
                             "roofline is fp32 vector issue; peak counts an FMA as 2 flops while the kernel is built without contraction"}
+
+    if rehearsal and rank == 0 and world > 1:
+        # the gathered frame must equal a frame rendered by one context alone
+        torch.cuda.synchronize()
+        gathered = rgb_host.numpy().copy()
+        ctx.set_partition(0, 1, STRIP_ROWS)
+        ctx.clear(); ctx.render_pass(0, args.spp); ctx.convert(1.0, srgb)
+        same = bool((ctx.read_image() == gathered).all())
+        ctx.set_partition(rank, world, STRIP_ROWS)
+        print(f"rehearsal: gathered frame of {world} ranks identical to a single-context frame: {same}", file=sys.stderr)
+        if not same:
+            sys.exit("rehearsal: multi-rank frame differs from the single-context frame")
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_spp > 0:
@@ -189,7 +215,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "reference scene file (baked), fixed seeds",
             "config": {"workload": f"scenes/final/frame0042.xml at {W}x{H}, {args.spp} spp in 1 pass, path-traced GI (BASELINE configs[3])",
                        "scene": args.scene, "width": W, "height": H, "spp": args.spp, "passes": 1,
-                       "parallelism": f"16-row image strips round-robin over {world} GPU(s), scene replicated, RGB8 rows gathered to rank 0"},
+                       "parallelism": f"{STRIP_ROWS}-row image strips round-robin over {world} GPU(s), scene replicated, RGB8 rows gathered to rank 0"},
             "rays_per_frame": rays_per_frame, "closest_rays": float(rays[1].item()), "shadow_rays": float(rays[2].item()),
             "frame_includes": "accumulator clear, trace kernel, ConvertColors, row gather, D2H of the 8-bit image",
             "scheduling": "tiles are handed out costliest first using the per-tile cost the previous frame measured (warm-up frame for the first timed one); results do not depend on the order",

@@ -16,6 +16,18 @@ def owned_rows(part, parts, height, strip_rows=16):
     return rows[(rows // strip_rows) % parts == part]
 
 
+_INDEX_CACHE = {}
+
+
+def _row_indices(parts, height, strip_rows, device):
+    """Index tensors of every rank's rows, built once per image shape and device."""
+    key = (parts, height, strip_rows, str(device))
+    if key not in _INDEX_CACHE:
+        _INDEX_CACHE[key] = [torch.as_tensor(owned_rows(p, parts, height, strip_rows), device=device, dtype=torch.long)
+                             for p in range(parts)]
+    return _INDEX_CACHE[key]
+
+
 def gather_rows(local, part, parts, strip_rows=16, dst=0, group=None):
     """Gather the owned rows of every rank's (H, W, C) tensor to rank `dst`.
 
@@ -24,7 +36,7 @@ def gather_rows(local, part, parts, strip_rows=16, dst=0, group=None):
     if parts == 1:
         return local
     H = local.shape[0]
-    idx = [torch.as_tensor(owned_rows(p, parts, H, strip_rows), device=local.device, dtype=torch.long) for p in range(parts)]
+    idx = _row_indices(parts, H, strip_rows, local.device)
     max_rows = max(int(i.numel()) for i in idx)
     packed = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     mine = idx[part]
