@@ -11,7 +11,8 @@
 // box-pair record (scene-node scan and BVH descent are the same operation);
 // LEAF: test one triangle; XFORM: enter a scene node or leave a mesh; PATH:
 // everything between two ray queries (shading, light and BSDF sampling, a new
-// camera ray); FETCH: take a pixel from the queue - and every lane carries the
+// camera ray; a lane whose pixel is finished first takes the next one from the
+// queue, in the same turn) - and every lane carries the
 // operation it needs next.  Each turn of the main loop the wave votes (ballot +
 // popcount) and executes one operation for the lanes that wait for it, so a
 // lane in a rare phase does not make the other 63 walk through its code;
@@ -273,7 +274,7 @@ DEV unsigned long long wave_sum(unsigned long long v) {
 //   XFORM  enter a scene node (world -> local, sphere / plane test or BVH root) or leave a mesh
 //   PATH   a query has ended or a pixel has just been fetched: shade / add the light sample /
 //          start the next query or the next path
-//   FETCH  take a pixel from the queue
+//   FETCH  the pixel is finished: the next PATH turn starts by taking a new one from the queue
 enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_XFORM = 2, S_PATH = 3, S_FETCH = 4, S_DONE = 5 };
 enum : uint32_t { H_NONE = 0, H_SPHERE = 1, H_PLANE = 2, H_MESH = 3 };
 enum : uint32_t { PK_NEW_PATH = 0, PK_CLOSEST_DONE = 1, PK_SHADOW_CLEAR = 2, PK_SHADOW_BLOCKED = 3 };
@@ -884,8 +885,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     for (;;) {
         // Which operation runs this turn.  Box steps are the bulk of the work and run whenever
         // sched_box_min lanes want one.  Otherwise a cheap traversal operation (triangle, transform)
-        // runs once sched_special_min lanes wait for it; failing that the fuller of box / path /
-        // fetch; leftovers last.
+        // runs once sched_special_min lanes wait for it; failing that the fuller of box and path (lanes
+        // that wait for a pixel count as path lanes: a path turn serves them first); leftovers last.
         uint32_t n_box = (uint32_t)__popcll(__ballot(state == S_BOX));
         // box burst: this inner loop carries only the few values a box step changes
         while (n_box >= S.sched_box_min) {
