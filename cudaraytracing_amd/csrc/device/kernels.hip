@@ -7,9 +7,9 @@
 // takes the next unowned pixel from a global queue with one wave-aggregated
 // atomic (ballot + mbcnt prefix), so lanes do not idle on short pixels.
 //
-// The work of a pixel is cut into five operations - BOX: slab-test one 64-byte
+// The work of a pixel is cut into four operations - BOX: slab-test one 64-byte
 // box-pair record (scene-node scan and BVH descent are the same operation);
-// LEAF: test one triangle; XFORM: enter a scene node or leave a mesh; PATH:
+// LEAF: test up to two triangles of a leaf; XFORM: enter a scene node or leave a mesh; PATH:
 // everything between two ray queries (shading, light and BSDF sampling, a new
 // camera ray; a lane whose pixel is finished first takes the next one from the
 // queue, in the same turn) - and every lane carries the
@@ -270,7 +270,7 @@ DEV unsigned long long wave_sum(unsigned long long v) {
 // ------------------------------------------------------------------ per-lane state
 // Operation a lane needs next.
 //   BOX    slab-test one box-pair record (scene-node scan or BVH interior node)
-//   LEAF   test one triangle of the pending leaf
+//   LEAF   test the next one or two triangles of the pending leaf
 //   XFORM  enter a scene node (world -> local, sphere / plane test or BVH root) or leave a mesh
 //   PATH   a query has ended or a pixel has just been fetched: shade / add the light sample /
 //          start the next query or the next path
