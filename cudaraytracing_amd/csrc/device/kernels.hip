@@ -918,7 +918,17 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         unsigned long long t_start = 0;
         if (kCount) t_start = __builtin_amdgcn_s_memtime();
         switch (best) {
-            case S_BOX: if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; } if (state == S_BOX) state = op_box(); break;
+            case S_BOX: {
+                // below the burst threshold: keep stepping while every lane that took the step wants another one
+                // (the lone lanes at the end of a frame are the common case), then vote again
+                uint32_t n_now;
+                do {
+                    if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; }
+                    if (state == S_BOX) state = op_box();
+                    n_now = (uint32_t)__popcll(__ballot(state == S_BOX));
+                } while (n_now == n_box);
+                break;
+            }
             case S_LEAF: if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); break;
             case S_XFORM: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_XFORM; } if (state == S_XFORM) state = op_xform(); break;
             default: {
