@@ -57,7 +57,7 @@ def profiled_traffic(args):
     the process, so the live line carries the figure of the profile, or null when the workload differs."""
     if (args.scene, args.width, args.height, args.spp, args.gpus) != ("final_frame0042", 1920, 1080, 64, 1):
         return None, "no committed counter pass for this workload"
-    path = os.path.join(ROOT, "profiles", "r01_v23_packed_64spp_rocprofv3.txt")
+    path = os.path.join(ROOT, "profiles", "r01_final_64spp_rocprofv3.txt")
     try:
         kib = {}
         for line in open(path):
