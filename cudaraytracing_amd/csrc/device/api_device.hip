@@ -408,7 +408,46 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     ctx->deep = stack_total > kLdsStackEntries;
     ctx->stack_overflow = ctx->deep ? stack_total - kLdsStackEntries : 0;
     S.stack_entries = ctx->deep ? kLdsStackEntries : stack_total;
-    S.sched_box_min = 16; S.sched_special_min = 6; S.sched_heavy_min = 1;      // measured optimum on the benchmark frame
+    {
+        // Drift bound of the scan's candidate mask.  One round trip through node j maps p to fl(tm * fl(itm * p)): its
+        // distance from p is at most |R p + r| (R = tm3 * itm3 - I, r = tm3 * t_itm + t_tm: the stored matrices are
+        // not exact inverses) plus the rounding of the two affine maps, 8.2 u |tm3| (|itm3| |p| + |t_itm|) + 4.1 u |t_tm|
+        // (u = 2^-24, four roundings per output).  A query enters every node at most once, so the sums over all
+        // object nodes bound the total drift; 5 % on top covers the growth of |p| along the way.
+        const double u = 1.0 / 16777216.0;
+        double rel = 0, abs_ = 0;
+        for (uint32_t i = 0; i < N; i++) {
+            const crt_node& n = d->nodes[i];
+            if (n.object_kind == CRT_OBJ_NONE) continue;
+            double nr = 0, nabs = 0, nrt = 0, nat = 0, nt = 0;
+            for (int row = 0; row < 3; row++) {
+                double r_row = 0, a_row = 0, rt = n.tm[9 + row], at = 0;
+                for (int col = 0; col < 3; col++) {
+                    double rc = 0, ac = 0;
+                    for (int k = 0; k < 3; k++) {
+                        rc += (double)n.tm[3 * k + row] * (double)n.itm[3 * col + k];
+                        ac += fabs((double)n.tm[3 * k + row]) * fabs((double)n.itm[3 * col + k]);
+                    }
+                    r_row += fabs(rc - (row == col ? 1.0 : 0.0));
+                    a_row += ac;
+                }
+                for (int k = 0; k < 3; k++) {
+                    rt += (double)n.tm[3 * k + row] * (double)n.itm[9 + k];
+                    at += fabs((double)n.tm[3 * k + row]) * fabs((double)n.itm[9 + k]);
+                }
+                nr = fmax(nr, r_row); nabs = fmax(nabs, a_row); nrt = fmax(nrt, fabs(rt)); nat = fmax(nat, at);
+                nt = fmax(nt, fabs((double)n.tm[9 + row]));
+            }
+            rel += nr + 9.0 * u * nabs;
+            abs_ += nrt + 9.0 * u * (nat + nt);
+        }
+        rel *= 1.05; abs_ *= 1.05;
+        const bool usable = N <= 64 && rel == rel && abs_ == abs_ && rel < 1e-3 && abs_ < 1e30;
+        S.scan_mask = usable ? 1u : 0u;
+        S.drift_rel = (float)rel * 1.000001f; S.drift_abs = (float)abs_ * 1.000001f;
+        if (const char* e = getenv("CRT_NO_SCAN_MASK")) if (atoi(e) != 0) S.scan_mask = 0;
+    }
+    S.sched_box_min = 12; S.sched_special_min = 6; S.sched_heavy_min = 24;     // measured optimum on the benchmark frame
     if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);
     if (const char* e = getenv("CRT_SCHED_SPECIAL_MIN")) S.sched_special_min = (uint32_t)atoi(e);
     if (const char* e = getenv("CRT_SCHED_HEAVY_MIN")) S.sched_heavy_min = (uint32_t)atoi(e);
@@ -690,6 +729,7 @@ int crt_get_stats(crt_ctx* ctx, crt_stats* out) {
     out->bvh_leaves = s.bvh_leaves; out->tri_tests = s.tri_tests; out->tri_hits = s.tri_hits;
     out->sphere_tests = s.sphere_tests; out->plane_tests = s.plane_tests; out->texel_quads = s.texel_quads;
     for (int k = 0; k < 8; k++) { out->sched_turns[k] = s.sched_turns[k]; out->sched_lanes[k] = s.sched_lanes[k]; out->sched_cycles[k] = s.sched_cycles[k]; out->path_cycles[k] = s.path_cycles[k]; }
+    out->scan_checks = s.scan_checks; out->scan_violations = s.scan_violations;
     return CRT_OK;
 }
 

@@ -115,6 +115,11 @@ struct DevScene {
     uint32_t sched_box_min;          // box steps run unconditionally while this many lanes of a wave want one
     uint32_t sched_special_min;      // a triangle / transform turn runs once this many lanes wait for it
     uint32_t sched_heavy_min;        // a path / fetch turn outvoting the box lanes needs this many lanes
+    // Candidate mask of the scene-node scan (see scan_candidates in kernels.hip).  drift_rel / drift_abs bound how
+    // far a ray can move over one whole query through the ToLocal / FromLocal round trips of the nodes it enters:
+    // |pos' - pos| <= drift_rel * max|pos| + drift_abs, |dir' - dir| <= drift_rel * max|dir| (per component).
+    uint32_t scan_mask;              // 1: the plain kernels scan candidates only (node_count <= 64 and small drift)
+    float drift_rel, drift_abs;
     const BoxPair* pairs;
     const TriRec* tris;
     const NodeXf* xf;
@@ -151,6 +156,7 @@ struct DevStats {
     unsigned long long tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
     unsigned long long sched_turns[8], sched_lanes[8], sched_cycles[8];
     unsigned long long path_cycles[8];
+    unsigned long long scan_checks, scan_violations;   // counted build: box hits of the scan checked against the candidate mask
 };
 
 }  // namespace crt

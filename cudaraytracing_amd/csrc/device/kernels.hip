@@ -100,6 +100,7 @@ struct Tally {
     uint32_t closest_rays, shadow_rays, paths;
     uint32_t node_box_tests, node_enters, bvh_interior, bvh_leaves, tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
     uint32_t turns[8], lanes[8];
+    uint32_t scan_checks, scan_violations;
     unsigned long long cycles[8];
 };
 #define TALLY(field) do { if (kCount) tally.field++; } while (0)
@@ -267,6 +268,66 @@ DEV unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// ------------------------------------------------------------------ candidate mask of the scene-node scan
+// The reference tests a ray against the box of every scene node in list order (renderer/trace.cu:51-68,
+// 166-193).  A node whose box is missed has no effect on the query, so the scan may skip any node that is
+// CERTAIN to be missed.  "Certain" has to hold for the ray as it will be when the scan reaches the node: every
+// node the ray enters sends it through ToLocal and FromLocal, which moves it by rounding errors.  S.drift_rel /
+// S.drift_abs bound that movement for a whole query, so a node is dropped only if the slab test fails for every
+// ray within that distance of the ray the query starts with:
+//   * the box is grown by the position bound;
+//   * an axis whose direction component is within 64 x the direction bound of zero puts no constraint on t
+//     (its sign, and with it the order of the two slab planes, could change);
+//   * on the other axes 1 / dir moves by less than 1 / 63 relative; entry and exit distance are widened by 1 / 32
+//     of their magnitude, which also covers the rounding of the test itself (x -> x +- |x| / 32 is monotone, so
+//     widening the maximum / minimum of the per-axis values is widening each of them);
+//   * the three acceptance conditions of Box::IntersectRay are then applied to the widened interval.
+// A shadow ray also leaves out the subtree of an object node that is certain to be missed, exactly as the scan
+// does for every object node it misses (trace.cu:171-185).  Bit i of the result: node i has to be tested.
+// The counted build does not scan by the mask; it checks every box hit of its full scan against it.
+DEV unsigned long long scan_candidates(const DevScene& S, const BoxPair* __restrict__ pairs, f3 pos, f3 dir, float tmax, bool shadow) {
+    const float pmax = fmaxf(fabsf(pos.x), fmaxf(fabsf(pos.y), fabsf(pos.z)));
+    const float dmax = fmaxf(fabsf(dir.x), fmaxf(fabsf(dir.y), fabsf(dir.z)));
+    const float dp = S.drift_rel * pmax + S.drift_abs;
+    const float dd = 64.0f * (S.drift_rel * dmax);
+    // anything not finite: test every node
+    if (!(pmax < 1e30f) || !(dmax < 1e30f) || !(dmax > 0.0f)) return ~0ull;
+    const bool cx = fabsf(dir.x) >= dd && fabsf(dir.x) > 1e-30f, cy = fabsf(dir.y) >= dd && fabsf(dir.y) > 1e-30f, cz = fabsf(dir.z) >= dd && fabsf(dir.z) > 1e-30f;
+    // unconstrained axis: (min - BIG) * 1 and (max + BIG) * 1 give -BIG and +BIG
+    const float big = 1e37f;
+    const f2 ox = cx ? f2{pos.x + dp, pos.x - dp} : f2{big, -big};
+    const f2 oy = cy ? f2{pos.y + dp, pos.y - dp} : f2{big, -big};
+    const f2 oz = cz ? f2{pos.z + dp, pos.z - dp} : f2{big, -big};
+    const float ix = cx ? 1.0f / dir.x : 1.0f, iy = cy ? 1.0f / dir.y : 1.0f, iz = cz ? 1.0f / dir.z : 1.0f;
+    const float wide = 1.0f / 32.0f;
+    uint32_t lo = 0, hi = 0;
+    uint32_t skip_until = 0;
+    auto one = [&](uint32_t i, uint32_t ref, f2 bx, f2 by, f2 bz) {
+        const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;
+        float t_in = fmaxf(fminf(tx.x, tx.y), fmaxf(fminf(ty.x, ty.y), fminf(tz.x, tz.y)));
+        float t_out = fminf(fmaxf(tx.x, tx.y), fminf(fmaxf(ty.x, ty.y), fmaxf(tz.x, tz.y)));
+        // (this is a filter, not path arithmetic: fused multiply-add is fine here)
+        t_in = __builtin_fmaf(-wide, fabsf(t_in), t_in - 1e-6f);
+        t_out = __builtin_fmaf(wide, fabsf(t_out), t_out + 1e-6f);
+        // a NaN bound (cannot arise from finite inputs) fails all three comparisons and so keeps the node
+        const bool cand = !((t_in > t_out) | (t_out < -2.0f * FLT_EPSILON) | (t_in > tmax));
+        const bool live = i >= skip_until;
+        const uint32_t bit = (live & cand) ? 1u << (i & 31u) : 0u;
+        if (i < 32u) lo |= bit; else hi |= bit;
+        if (shadow & live & !cand) skip_until = node_ref_after(ref);
+    };
+    // The node records never change during a launch and the index is the same in every lane: they are read through
+    // the constant address space, i.e. with scalar loads; record i holds nodes i and i + 1.
+    const __attribute__((address_space(4))) BoxPair* recs = reinterpret_cast<const __attribute__((address_space(4))) BoxPair*>(reinterpret_cast<uintptr_t>(pairs));
+    for (uint32_t i = 0; i < S.node_count; i += 2) {
+        const __attribute__((address_space(4))) BoxPair& rec = recs[i];
+        const uint32_t ref_a = rec.ref_a, ref_b = rec.ref_b;
+        if (node_ref_kind(ref_a) != CRT_OBJ_NONE) one(i, ref_a, f2{rec.a[0], rec.a[1]}, f2{rec.a[2], rec.a[3]}, f2{rec.a[4], rec.a[5]});
+        if (node_ref_kind(ref_b) != CRT_OBJ_NONE) one(i + 1, ref_b, f2{rec.b[0], rec.b[1]}, f2{rec.b[2], rec.b[3]}, f2{rec.b[4], rec.b[5]});
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // ------------------------------------------------------------------ per-lane state
 // Operation a lane needs next.
 //   BOX    slab-test one box-pair record (scene-node scan or BVH interior node)
@@ -294,6 +355,7 @@ struct Lane {
     DEV void set_qdir(f3 d) { pdx.y = d.x; pdy.y = d.y; pdz.y = d.z; }
     float limit;                    // slab t_max: FLT_MAX for closest hit, the light distance for shadow rays
     uint32_t node;                  // next scene node to scan
+    unsigned long long mask;        // scene nodes the scan still has to test (bit i = node i), when it runs by candidates
     uint32_t cur;                   // BVH record to expand
     uint32_t sp;                    // LDS stack height
     uint32_t entered;               // scene node whose mesh is being traversed
@@ -347,6 +409,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const BoxPair* __restrict__ pairs = S.pairs;
     const TriRec* __restrict__ tris = S.tris;
     const uint32_t node_count = S.node_count;
+    // the plain kernels scan the candidate nodes only; the counted one scans every node, as the reference does, and
+    // checks its box hits against the mask
+    const bool by_mask = !kCount && S.scan_mask != 0;
 
     Tally tally = {};
     // counted build: when the wave started / first found the queue dry (per wave, in LDS)
@@ -378,6 +443,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     // the query has run out of scene nodes
     auto query_done = [&]() -> uint32_t { L.pk = L.shadow ? PK_SHADOW_CLEAR : PK_CLOSEST_DONE; return S_PATH; };
     auto shadow_blocked = [&]() -> uint32_t { L.pk = PK_SHADOW_BLOCKED; return S_PATH; };
+    auto first_candidate = [&]() -> uint32_t { return L.mask ? (uint32_t)__ffsll((long long)L.mask) - 1u : node_count; };
     auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_BOX : query_done(); };
 
     // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
@@ -429,12 +495,41 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         const uint32_t kind_a = node_ref_kind(ref_a), kind_b = node_ref_kind(ref_b);
         const uint32_t after_a = node_ref_after(ref_a), after_b = node_ref_after(ref_b);
         const bool sh = L.shadow;
+        if (by_mask) {
+            // Scan by candidates: half A is the lowest candidate, half B is looked at when it is one too.  Nodes in
+            // between were certain misses; a candidate object node that a shadow ray misses takes its subtree along.
+            const uint32_t i = L.node;
+            const bool enter_a = hitA & (sh | (tA < L.hz));
+            unsigned long long m = L.mask & ~(1ull << i);
+            if (sh & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << i) - 1ull);
+            const bool cand_b = !enter_a & (i < 63u) & (((m >> ((i + 1u) & 63u)) & 1ull) != 0);
+            const bool enter_b = cand_b & hitB & (sh | (tB < L.hz));
+            if (cand_b) {
+                m &= ~(2ull << i);
+                if (sh & !hitB) m &= ~(((1ull << (after_b & 63u)) - 1ull) | (after_b >= 64u ? ~0ull : 0ull)) | ((4ull << i) - 1ull);
+            }
+            L.mask = m;
+            if (enter_a | enter_b) {
+                L.pend = enter_a ? (i | (kind_a << 30)) : ((i + 1u) | (kind_b << 30));
+                return S_XFORM;
+            }
+            L.node = first_candidate();
+            return after_scan();
+        }
         const bool obj_a = kind_a != CRT_OBJ_NONE, obj_b = kind_b != CRT_OBJ_NONE;
         const bool enter_a = obj_a & hitA & (sh | (tA < L.hz));
         const bool jump_a = sh & obj_a & (after_a != L.node + 1);            // shadow ray past a missed subtree
         const bool look_b = !(enter_a | jump_a);
         const bool enter_b = look_b & obj_b & hitB & (sh | (tB < L.hz));
-        if (kCount) { tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b & obj_b) ? 1u : 0u); }
+        if (kCount) {
+            tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b & obj_b) ? 1u : 0u);
+            // every box the full scan finds hit must be a candidate of the mask the plain kernels scan by
+            if (S.scan_mask) {
+                const bool chk_a = obj_a & hitA, chk_b = look_b & obj_b & hitB;
+                tally.scan_checks += (chk_a ? 1u : 0u) + (chk_b ? 1u : 0u);
+                tally.scan_violations += ((chk_a && !((L.mask >> (L.node & 63u)) & 1ull)) ? 1u : 0u) + ((chk_b && !((L.mask >> ((L.node + 1u) & 63u)) & 1ull)) ? 1u : 0u);
+            }
+        }
         if (enter_a | enter_b) {
             L.pend = enter_a ? (L.node | (kind_a << 30)) : ((L.node + 1) | (kind_b << 30));
             return S_XFORM;
@@ -564,7 +659,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         }
         xform_ray(tm, L.pdx, L.pdy, L.pdz);
         L.qinv = recip3(L.qdir());
-        L.node = idx + 1;
+        L.node = by_mask ? first_candidate() : idx + 1;
         return after_scan();
     };
 
@@ -877,6 +972,13 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         cold_st(C_SAMPLE, (uint32_t)sample);
         cold_st(C_SEGMENTS, segments);
         cold_st(C_COST, cost + 1);
+        // one pass over the node boxes for whichever query the lane is about to start
+        if (S.scan_mask && next_state == S_BOX) {
+            L.mask = scan_candidates(S, pairs, L.qpos(), L.qdir(), L.limit, L.shadow);
+            if (by_mask) L.node = first_candidate();
+        }
+        // no node of the scene can be hit at all: the query is over before its first box step
+        if (by_mask && next_state == S_BOX && L.node >= node_count) next_state = query_done();
         SECT(5);
         return next_state;
     };
@@ -976,12 +1078,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
 
     // ---- counters: one atomic per wave and field
     const unsigned long long c_closest = wave_sum(tally.closest_rays), c_shadow = wave_sum(tally.shadow_rays);
+    unsigned long long c_sc = 0, c_sv = 0;
     unsigned long long c_paths = 0, c_nb = 0, c_ne = 0, c_bi = 0, c_bl = 0, c_tt = 0, c_th = 0, c_sp = 0, c_pl = 0, c_tx = 0;
     if (kCount) {
         c_paths = wave_sum(tally.paths); c_nb = wave_sum(tally.node_box_tests); c_ne = wave_sum(tally.node_enters);
         c_bi = wave_sum(tally.bvh_interior); c_bl = wave_sum(tally.bvh_leaves); c_tt = wave_sum(tally.tri_tests);
         c_th = wave_sum(tally.tri_hits); c_sp = wave_sum(tally.sphere_tests); c_pl = wave_sum(tally.plane_tests);
         c_tx = wave_sum(tally.texel_quads);
+        c_sc = wave_sum(tally.scan_checks); c_sv = wave_sum(tally.scan_violations);
     }
     if (!kPrimary && (threadIdx.x & 63u) == 0) {
         atomicAdd(&stats->closest_rays, c_closest);
@@ -991,6 +1095,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             atomicAdd(&stats->bvh_interior, c_bi); atomicAdd(&stats->bvh_leaves, c_bl); atomicAdd(&stats->tri_tests, c_tt);
             atomicAdd(&stats->tri_hits, c_th); atomicAdd(&stats->sphere_tests, c_sp); atomicAdd(&stats->plane_tests, c_pl);
             atomicAdd(&stats->texel_quads, c_tx);
+            atomicAdd(&stats->scan_checks, c_sc); atomicAdd(&stats->scan_violations, c_sv);
         }
     }
     if (kCount && !kPrimary) {

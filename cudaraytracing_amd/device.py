@@ -85,6 +85,12 @@ class Context:
         self._check(capi.lib().crt_get_stats(self._h, C.byref(s)))
         return s.schedule()
 
+    def scan_check(self):
+        """Counted pass: scene-node boxes found hit and how many of them the candidate mask would have dropped (must be 0)."""
+        s = capi.Stats()
+        self._check(capi.lib().crt_get_stats(self._h, C.byref(s)))
+        return {"checks": int(s.scan_checks), "violations": int(s.scan_violations)}
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._check(capi.lib().crt_last_kernel_ms(self._h, C.byref(ms)))

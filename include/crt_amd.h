@@ -277,6 +277,8 @@ typedef struct crt_stats {
     uint64_t path_cycles[8];    /* cycles inside the path operation: lights, hit attributes, textures,
                                    light sampling, BSDF sampling, next ray; [6] summed wave
                                    lifetimes, [7] the part of them after the pixel queue ran dry */
+    uint64_t scan_checks;       /* scene-node boxes the counted pass found hit, each checked against the */
+    uint64_t scan_violations;   /* candidate mask the plain pass scans by; a violation would be a parity bug */
 } crt_stats;
 
 int crt_get_stats(crt_ctx* ctx, crt_stats* out);

@@ -34,7 +34,7 @@ def test_struct_sizes_match_the_c_side():
     assert ctypes.sizeof(capi.Node) == 136
     assert ctypes.sizeof(capi.Material) == 36
     assert ctypes.sizeof(capi.Light) == 32
-    assert ctypes.sizeof(capi.Stats) == 96 + 256
+    assert ctypes.sizeof(capi.Stats) == 96 + 256 + 16
 
 
 def test_error_paths_without_compute(tmp_path):

@@ -330,3 +330,25 @@ def test_renderer_front_end(gpu_ctx, tmp_path):
     assert img.SaveImage(tmp_path / "out.png")
     from PIL import Image
     assert np.array_equal(np.asarray(Image.open(tmp_path / "out.png")), img.pixels)
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("final_frame0042", 384, 216, 4), ("proj5_box", 320, 180, 4), ("proj7_checkerboard", 320, 180, 8),
+                                           ("proj4_box", 320, 180, 4), ("teapot_low_box", 640, 360, 2), ("final_frame0001", 256, 144, 2),
+                                           ("proj13_box", 320, 180, 4), ("proj1_snowman", 320, 180, 2), ("proj5_plane", 320, 180, 4)])
+def test_scan_candidate_mask_never_drops_a_hit(gpu_ctx, name, w, h, spp):
+    """The plain kernels scan only the scene nodes a conservative test cannot rule out.  The counted kernel scans
+    every node, as the reference does, and checks each box it finds hit against that mask: no violation may occur,
+    and the two kernels must produce the same accumulators."""
+    s = crt.Scene.load_file(scene_path(name))
+    s.set_resolution(w, h)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, spp)
+    plain = [a.copy() for a in gpu_ctx.read_accumulators()]
+    gpu_ctx.clear()
+    gpu_ctx.render_pass_counted(0, spp)
+    counted = gpu_ctx.read_accumulators()
+    for a, b in zip(plain, counted):
+        assert same(a, b)
+    st = gpu_ctx.scan_check()
+    assert st["checks"] > 0 and st["violations"] == 0

@@ -33,6 +33,10 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tests/golden/scenes/*.crtscene"
         # rows of other ranks stay untouched
         other = np.setdiff1d(np.arange(h), rows)
         ok = ok and all(not acc[k][other].any() for k in range(3))
+        # the counted pass scans every node and checks its box hits against the candidate mask of the plain pass
+        ctx.clear(); ctx.render_pass_counted(p0, spp)
+        chk = ctx.scan_check()
+        ok = ok and chk["violations"] == 0
         bad += not ok
         print(f"{'ok ' if ok else 'BAD'} {name:28s} {w}x{h} spp {spp} passes {p0}..{p0 + passes - 1} part {part}/{parts} strip {strip}", flush=True)
 print("mismatching cases:", bad)
