@@ -446,6 +446,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         S.scan_mask = usable ? 1u : 0u;
         S.drift_rel = (float)rel * 1.000001f; S.drift_abs = (float)abs_ * 1.000001f;
         if (const char* e = getenv("CRT_NO_SCAN_MASK")) if (atoi(e) != 0) S.scan_mask = 0;
+        // profiling only: the counted build then scans by the mask too (its node counters no longer match the reference's)
+        if (const char* e = getenv("CRT_COUNTED_BY_MASK")) if (atoi(e) != 0 && S.scan_mask) S.scan_mask = 3;
     }
     S.sched_box_min = 12; S.sched_special_min = 6; S.sched_heavy_min = 24;     // measured optimum on the benchmark frame
     if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);

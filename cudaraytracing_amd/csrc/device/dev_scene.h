@@ -118,7 +118,7 @@ struct DevScene {
     // Candidate mask of the scene-node scan (see scan_candidates in kernels.hip).  drift_rel / drift_abs bound how
     // far a ray can move over one whole query through the ToLocal / FromLocal round trips of the nodes it enters:
     // |pos' - pos| <= drift_rel * max|pos| + drift_abs, |dir' - dir| <= drift_rel * max|dir| (per component).
-    uint32_t scan_mask;              // 1: the plain kernels scan candidates only (node_count <= 64 and small drift)
+    uint32_t scan_mask;              // bit 0: the plain kernels scan candidates only (node_count <= 64 and small drift)
     float drift_rel, drift_abs;
     const BoxPair* pairs;
     const TriRec* tris;

@@ -300,9 +300,12 @@ DEV unsigned long long scan_candidates(const DevScene& S, const BoxPair* __restr
     const f2 oz = cz ? f2{pos.z + dp, pos.z - dp} : f2{big, -big};
     const float ix = cx ? 1.0f / dir.x : 1.0f, iy = cy ? 1.0f / dir.y : 1.0f, iz = cz ? 1.0f / dir.z : 1.0f;
     const float wide = 1.0f / 32.0f;
-    uint32_t lo = 0, hi = 0;
     uint32_t skip_until = 0;
-    auto one = [&](uint32_t i, uint32_t ref, f2 bx, f2 by, f2 bz) {
+    // The node records never change during a launch and the index is the same in every lane: they are read through
+    // the constant address space, i.e. with scalar loads, a whole 64-byte record (nodes i and i + 1) at a time.
+    typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+    const __attribute__((address_space(4))) u16v* recs = reinterpret_cast<const __attribute__((address_space(4))) u16v*>(reinterpret_cast<uintptr_t>(pairs));
+    auto one = [&](uint32_t word, uint32_t i, uint32_t ref, f2 bx, f2 by, f2 bz) -> uint32_t {
         const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;
         float t_in = fmaxf(fminf(tx.x, tx.y), fmaxf(fminf(ty.x, ty.y), fminf(tz.x, tz.y)));
         float t_out = fminf(fmaxf(tx.x, tx.y), fminf(fmaxf(ty.x, ty.y), fmaxf(tz.x, tz.y)));
@@ -312,19 +315,23 @@ DEV unsigned long long scan_candidates(const DevScene& S, const BoxPair* __restr
         // a NaN bound (cannot arise from finite inputs) fails all three comparisons and so keeps the node
         const bool cand = !((t_in > t_out) | (t_out < -2.0f * FLT_EPSILON) | (t_in > tmax));
         const bool live = i >= skip_until;
-        const uint32_t bit = (live & cand) ? 1u << (i & 31u) : 0u;
-        if (i < 32u) lo |= bit; else hi |= bit;
         if (shadow & live & !cand) skip_until = node_ref_after(ref);
+        return word | ((live & cand) ? 1u << (i & 31u) : 0u);
     };
-    // The node records never change during a launch and the index is the same in every lane: they are read through
-    // the constant address space, i.e. with scalar loads; record i holds nodes i and i + 1.
-    const __attribute__((address_space(4))) BoxPair* recs = reinterpret_cast<const __attribute__((address_space(4))) BoxPair*>(reinterpret_cast<uintptr_t>(pairs));
-    for (uint32_t i = 0; i < S.node_count; i += 2) {
-        const __attribute__((address_space(4))) BoxPair& rec = recs[i];
-        const uint32_t ref_a = rec.ref_a, ref_b = rec.ref_b;
-        if (node_ref_kind(ref_a) != CRT_OBJ_NONE) one(i, ref_a, f2{rec.a[0], rec.a[1]}, f2{rec.a[2], rec.a[3]}, f2{rec.a[4], rec.a[5]});
-        if (node_ref_kind(ref_b) != CRT_OBJ_NONE) one(i + 1, ref_b, f2{rec.b[0], rec.b[1]}, f2{rec.b[2], rec.b[3]}, f2{rec.b[4], rec.b[5]});
-    }
+    auto as_f = [](uint32_t v) { return __uint_as_float(v); };
+    auto half = [&](uint32_t first, uint32_t last) -> uint32_t {
+        uint32_t word = 0;
+        for (uint32_t i = first; i < last; i += 2) {
+            const u16v r = recs[i];
+            const uint32_t ref_a = r[12], ref_b = r[13];
+            if (node_ref_kind(ref_a) != CRT_OBJ_NONE) word = one(word, i, ref_a, f2{as_f(r[0]), as_f(r[1])}, f2{as_f(r[2]), as_f(r[3])}, f2{as_f(r[4]), as_f(r[5])});
+            if (node_ref_kind(ref_b) != CRT_OBJ_NONE) word = one(word, i + 1, ref_b, f2{as_f(r[6]), as_f(r[7])}, f2{as_f(r[8]), as_f(r[9])}, f2{as_f(r[10]), as_f(r[11])});
+        }
+        return word;
+    };
+    const uint32_t n = S.node_count;
+    const uint32_t lo = half(0, n < 32u ? n : 32u);
+    const uint32_t hi = n > 32u ? half(32, n) : 0u;
     return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const uint32_t node_count = S.node_count;
     // the plain kernels scan the candidate nodes only; the counted one scans every node, as the reference does, and
     // checks its box hits against the mask
-    const bool by_mask = !kCount && S.scan_mask != 0;
+    const bool by_mask = S.scan_mask != 0 && (!kCount || (S.scan_mask & 2u) != 0);      // bit 1: profiling, the counted build follows the mask too
 
     Tally tally = {};
     // counted build: when the wave started / first found the queue dry (per wave, in LDS)
