@@ -449,7 +449,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         // profiling only: the counted build then scans by the mask too (its node counters no longer match the reference's)
         if (const char* e = getenv("CRT_COUNTED_BY_MASK")) if (atoi(e) != 0 && S.scan_mask) S.scan_mask = 3;
     }
-    S.sched_box_min = 12; S.sched_special_min = 6; S.sched_heavy_min = 24;     // measured optimum on the benchmark frame
+    // measured optima: 12 / 6 / 24 on the benchmark frame; a deep BVH (the ten-million-triangle scene) prefers 16
+    S.sched_box_min = ctx->deep ? 16 : 12; S.sched_special_min = 6; S.sched_heavy_min = 24;
     if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);
     if (const char* e = getenv("CRT_SCHED_SPECIAL_MIN")) S.sched_special_min = (uint32_t)atoi(e);
     if (const char* e = getenv("CRT_SCHED_HEAVY_MIN")) S.sched_heavy_min = (uint32_t)atoi(e);
