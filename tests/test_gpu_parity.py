@@ -352,3 +352,63 @@ def test_scan_candidate_mask_never_drops_a_hit(gpu_ctx, name, w, h, spp):
         assert same(a, b)
     st = gpu_ctx.scan_check()
     assert st["checks"] > 0 and st["violations"] == 0
+
+
+def _nested_scene_xml(seed):
+    """A scene graph three levels deep: object nodes with object children (the scan's subtree skip for shadow rays),
+    rotations and non-uniform scales (ray drift through ToLocal / FromLocal), planes and spheres, two point lights."""
+    rs = np.random.RandomState(seed)
+    def obj(depth, idx):
+        kind = "plane" if rs.rand() < 0.2 else "sphere"
+        s = rs.uniform(0.4, 1.6, 3) * (3.0 if depth == 0 else 0.6)
+        t = rs.uniform(-6, 6, 3) if depth == 0 else rs.uniform(-1.5, 1.5, 3)
+        axis = rs.uniform(-1, 1, 3)
+        out = [f'<object type="{kind}" name="o{depth}_{idx}" material="m{int(rs.randint(0, 3))}">',
+               f'<scale x="{s[0]:.4f}" y="{s[1]:.4f}" z="{s[2]:.4f}"/>',
+               f'<rotate angle="{rs.uniform(0, 360):.3f}" x="{axis[0]:.4f}" y="{axis[1]:.4f}" z="{axis[2]:.4f}"/>',
+               f'<translate x="{t[0]:.4f}" y="{t[1]:.4f}" z="{t[2]:.4f}"/>']
+        if depth < 2:
+            for k in range(int(rs.randint(1, 4))):
+                out += obj(depth + 1, idx * 10 + k)
+        out.append("</object>")
+        return out
+    body = []
+    for k in range(5):
+        body += obj(0, k)
+    body.append('<object type="plane" name="floor" material="m0"><scale value="40"/><translate z="-8"/></object>')
+    mats = ['<material type="blinn" name="m0"><diffuse r="0.8" g="0.7" b="0.6"/><specular value="0.2"/><glossiness value="20"/></material>',
+            '<material type="blinn" name="m1"><diffuse r="0.2" g="0.5" b="0.8"/><specular value="0.7"/><glossiness value="60"/></material>',
+            '<material type="blinn" name="m2"><diffuse value="0.05"/><specular value="0.1"/><glossiness value="100"/>'
+            '<refraction value="0.85" index="1.5"/><absorption r="0.02" g="0.01" b="0.03"/></material>']
+    lights = ['<light type="point" name="l0"><intensity value="500"/><position x="10" y="-12" z="14"/><size value="2"/></light>',
+              '<light type="point" name="l1"><intensity value="200"/><position x="-9" y="-6" z="9"/><size value="1"/></light>']
+    cam = ('<camera><position x="0" y="-26" z="9"/><target x="0" y="0" z="-1"/><up x="0" y="0" z="1"/><fov value="42"/>'
+           '<width value="256"/><height value="160"/></camera>')
+    return "<xml><scene>" + "".join(body + mats + lights) + "</scene>" + cam + "</xml>"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_nested_scene_graph_is_bit_exact(gpu_ctx, tmp_path, seed):
+    xml = tmp_path / f"nested{seed}.xml"
+    xml.write_text(_nested_scene_xml(seed))
+    s = crt.Scene.load_xml(str(xml))
+    assert 20 < s.desc().node_count <= 64
+    flat = str(tmp_path / f"nested{seed}.crtscene")
+    s.save_file(flat)
+    o = orc.OracleScene(flat)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, 4)
+    acc = gpu_ctx.read_accumulators()
+    ref, cnt = o.render(0, 4, count=True)
+    for k, n in enumerate(("results", "normals", "albedos")):
+        assert same(acc[k], ref[k]), n
+    st = gpu_ctx.stats()
+    assert (st["closest_rays"], st["shadow_rays"]) == (cnt["closest_rays"], cnt["shadow_rays"])
+    gpu_ctx.clear()
+    gpu_ctx.render_pass_counted(0, 4)
+    assert same(gpu_ctx.read_accumulators()[0], ref[0])
+    chk = gpu_ctx.scan_check()
+    assert chk["checks"] > 0 and chk["violations"] == 0
+    full = gpu_ctx.stats(); full.pop("texel_quads"); cnt.pop("texel_quads")
+    assert full == cnt
