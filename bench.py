@@ -223,7 +223,7 @@ def main():
             "metric": "Mrays/s (scenes/final, 1080p, 64 spp)", "value": rays_per_frame / (ms_per_step * 1e-3) * 1e-6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "reference scene file (baked), fixed seeds",
-            "config": {"workload": f"scenes/final/frame0042.xml at {W}x{H}, {args.spp} spp in 1 pass, path-traced GI (BASELINE configs[3])",
+            "config": {"workload": f"scenes/final/frame0042.xml at {W}x{H}, {args.spp} spp in 1 pass, path-traced GI (BASELINE.json configs[3])",
                        "scene": args.scene, "width": W, "height": H, "spp": args.spp, "passes": 1,
                        "parallelism": f"{STRIP_ROWS}-row image strips round-robin over {world} GPU(s), scene replicated, RGB8 rows gathered to rank 0"},
             "rays_per_frame": rays_per_frame, "closest_rays": float(rays[1].item()), "shadow_rays": float(rays[2].item()),

@@ -76,7 +76,7 @@ def test_primary_hits_equal_golden(gpu_ctx, name):
 @pytest.mark.parametrize("name,w,h", [("proj1_ball", 1280, 720), ("proj5_glasspot", 640, 360), ("final_frame0001", 640, 360),
                                       ("proj7_checkerboard", 640, 360), ("final_frame0042", 640, 360)])
 def test_primary_hits_equal_oracle(gpu_ctx, name, w, h):
-    """BASELINE config 1 (proj1 sphere scene, primary rays, scene resolution) and the mesh scenes."""
+    """BASELINE.json configs[0] (proj1 sphere scene, primary rays, scene resolution) and the mesh scenes."""
     s, o = load_both(name, w, h)
     gpu_ctx.upload(s)
     for p in (0, 3):
@@ -103,16 +103,16 @@ def test_accumulators_equal_golden(gpu_ctx, name, spp):
 
 CASES = [
     ("proj4_box", 320, 180, 4),            # spheres, ambient + point light, refraction
-    ("teapot_low_box", 1280, 720, 1),      # BASELINE config 2: teapot-low BVH, shadows, 1 spp, scene resolution
+    ("teapot_low_box", 1280, 720, 1),      # BASELINE.json configs[1]: teapot-low BVH, shadows, 1 spp, scene resolution
     ("proj5_box", 320, 180, 4),            # two teapot.obj instances, NEE through a mesh
     ("proj5_glasspot", 256, 144, 2),       # 86 nodes, hollow teapot, nested transforms
-    ("proj7_checkerboard", 320, 180, 16),  # BASELINE config 3 at reduced size: textures, glossy + refractive, 16 spp
+    ("proj7_checkerboard", 320, 180, 16),  # BASELINE.json configs[2] at reduced size: textures, glossy + refractive, 16 spp
     ("proj13_box", 320, 180, 4),
     ("final_frame0001", 256, 144, 2),
-    ("final_frame0042", 320, 180, 4),      # BASELINE config 4 scene: 20 meshes, dof, sRGB
+    ("final_frame0042", 320, 180, 4),      # BASELINE.json configs[3] scene: 20 meshes, dof, sRGB
     ("proj5_plane", 320, 180, 4),
     ("proj1_snowman", 320, 180, 2),        # no lights at all: no light sample is taken
-    ("proj7_checkerboard", 1280, 720, 16), # BASELINE config 3 at its full size
+    ("proj7_checkerboard", 1280, 720, 16), # BASELINE.json configs[2] at its full size
 ]
 
 
@@ -133,7 +133,7 @@ def test_render_is_bit_exact(gpu_ctx, name, w, h, spp):
 
 
 def test_instanced_scene_is_bit_exact(gpu_ctx, tmp_path):
-    """BASELINE config 5 at reduced size: copies of teapot.obj flattened into one mesh (126 k triangles,
+    """BASELINE.json configs[4] at reduced size: copies of teapot.obj flattened into one mesh (126 k triangles,
     BVH depth 22, so the traversal stack in LDS is deeper than on any shipped scene), floor, point light."""
     src = crt.Scene.load_file(scene_path("proj5_box"))
     syn = src.make_instanced(0, 20, seed=1, width=192, height=108)
@@ -239,7 +239,7 @@ def test_tolerance_against_glibc_flavour(gpu_ctx):
 
 
 def test_full_size_frame_properties(gpu_ctx):
-    """BASELINE config 4 at full size (frame0042, 1920x1080): strips checked against the oracle,
+    """BASELINE.json configs[3] at full size (frame0042, 1920x1080): strips checked against the oracle,
     the whole frame through size-independent properties."""
     s, o = load_both("final_frame0042", 1920, 1080)
     gpu_ctx.upload(s)

@@ -186,7 +186,7 @@ def test_png_round_trip(tmp_path):
 
 
 def test_instanced_scene_generator(tmp_path):
-    """The synthetic instanced scene (BASELINE config 5 at reduced size) is a fixed function of its arguments,
+    """The synthetic instanced scene (BASELINE.json configs[4] at reduced size) is a fixed function of its arguments,
     survives the flat-file round trip, and its BVH (deeper than any shipped mesh) equals the oracle's."""
     import hashlib
     src = crt.Scene.load_file(scene_path("proj5_box"))
