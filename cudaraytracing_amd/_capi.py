@@ -107,6 +107,7 @@ _PROTOS = {
     "crt_clear": (C.c_int, [_VP]),
     "crt_clear_async": (C.c_int, [_VP, _VP]),
     "crt_render_pass": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int]),
+    "crt_render_pass_noalloc": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int]),
     "crt_convert": (C.c_int, [_VP, C.c_float, C.c_int, _VP, _VP, C.c_int]),
     "crt_prepare_denoise": (C.c_int, [_VP, C.c_float, _VP, _VP, _VP, _VP, C.c_int]),
     "crt_convert_floats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int]),

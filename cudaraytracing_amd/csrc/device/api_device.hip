@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,10 +40,20 @@ struct crt_ctx {
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};   // event pair per launch, ring buffer
     uint64_t launches = 0;                          // launches recorded so far
     uint64_t reported = 0;                          // launches already handed out by crt_kernel_times
+    unsigned char* scratch = nullptr;          // this device's copy of the static workspace (crt_render_pass_noalloc)
+    std::map<int, std::vector<uint32_t>> host_jumps;   // pass -> jump matrix on the host, for the call that allocates nothing
     int num_cus = 0;
     size_t lds_bytes = 0;
     int blocks_per_cu = 0, blocks_per_cu_counted = 0;
 };
+
+// Workspace of crt_render_pass_noalloc: the pixel-queue counter, one sequence-jump matrix and the per-lane path
+// state of the trace kernel, in a fixed array of the code object instead of memory from hipMalloc.  Every GPU the
+// library runs on holds its own copy at its own address until the process ends; host code never uses the array's
+// name as an address, only the pointer hipGetSymbolAddress returned for the device in use (scratch_for_device).
+constexpr size_t kScratchBytes = 32u << 20;
+constexpr size_t kScratchQueueOff = 0, kScratchJumpOff = 256, kScratchStateOff = 4096;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 namespace {
 
@@ -56,6 +67,23 @@ namespace {
     } while (0)
 
 int fail(crt_ctx* ctx, int code, const std::string& msg) { ctx->error = msg; return code; }
+
+// Device address of `scratch` on the current device, looked up once per device.
+hipError_t scratch_for_device(int device, unsigned char** out) {
+    static std::mutex lock;
+    static std::map<int, unsigned char*> known;
+    std::lock_guard<std::mutex> guard(lock);
+    auto it = known.find(device);
+    if (it == known.end()) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        it = known.emplace(device, (unsigned char*)p).first;
+    }
+    *out = it->second;
+    return hipSuccess;
+}
 
 void free_scene(crt_ctx* ctx) {
     for (void* p : ctx->allocs) (void)hipFree(p);
@@ -238,6 +266,9 @@ int crt_create(int device, crt_ctx** out) {
         delete ctx; crt::set_host_error("cannot select HIP device"); return CRT_E_HIP;
     }
     ctx->num_cus = prop.multiProcessorCount;
+    if (scratch_for_device(device, &ctx->scratch) != hipSuccess) {
+        delete ctx; crt::set_host_error("cannot resolve the static workspace on this device"); return CRT_E_HIP;
+    }
     if (hipMalloc((void**)&ctx->queue, 256) != hipSuccess || hipMalloc((void**)&ctx->stats, sizeof(DevStats)) != hipSuccess ||
         hipMemset(ctx->stats, 0, sizeof(DevStats)) != hipSuccess) {
         delete ctx; crt::set_host_error("cannot allocate context buffers"); return CRT_E_HIP;
@@ -590,6 +621,53 @@ int crt_render_pass(crt_ctx* ctx, int pass_id, int samples, void* stream, int as
 
 int crt_render_pass_counted(crt_ctx* ctx, int pass_id, int samples) {
     return render_impl(ctx, pass_id, samples, nullptr, false, true);
+}
+
+int crt_render_pass_noalloc(crt_ctx* ctx, int pass_id, int samples, void* stream_, int async) {
+    if (!ctx) return CRT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
+    if (pass_id < 0 || samples <= 0) return fail(ctx, CRT_E_INVALID, "pass_id must be >= 0 and samples > 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->P.total_items == 0) return CRT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    // the grid is cut down to the lanes whose path state fits the workspace
+    const size_t lane_bytes = (C_WORDS + 2ull * ctx->stack_overflow) * 4;
+    const size_t blocks_fit = (kScratchBytes - kScratchStateOff) / (lane_bytes * CRT_BLOCK);
+    if (blocks_fit < 1)
+        return fail(ctx, CRT_E_LIMIT, "scene needs " + std::to_string(lane_bytes * CRT_BLOCK) + " bytes of path state per block, the static workspace holds " +
+                                      std::to_string(kScratchBytes - kScratchStateOff));
+    uint32_t grid = (uint32_t)(ctx->num_cus * ctx->blocks_per_cu);
+    const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
+    if (grid > need) grid = need;
+    if (grid > blocks_fit) grid = (uint32_t)blocks_fit;
+    unsigned char* ws = ctx->scratch;
+    const uint32_t* jump = nullptr;
+    if (pass_id > 0) {
+        auto it = ctx->host_jumps.find(pass_id);
+        if (it == ctx->host_jumps.end()) {
+            BitMat m;
+            jump_for_pass((unsigned)pass_id, m);
+            it = ctx->host_jumps.emplace(pass_id, std::vector<uint32_t>(&m.row[0][0], &m.row[0][0] + 800)).first;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ws + kScratchJumpOff, it->second.data(), 3200, hipMemcpyHostToDevice, stream));
+        jump = (const uint32_t*)(ws + kScratchJumpOff);
+    }
+    // the workspace keeps what the previous call left: the queue counter has to start at zero (the path state is
+    // written before it is read, pixel by pixel)
+    HIP_TRY(ctx, hipMemsetAsync(ws + kScratchQueueOff, 0, 256, stream));
+    DevPartition P = ctx->P;
+    P.tile_cost = nullptr; P.tile_order = nullptr;      // storage order: the balance tables belong to crt_render_pass
+    uint32_t* queue = (uint32_t*)(ws + kScratchQueueOff);
+    uint32_t* state = (uint32_t*)(ws + kScratchStateOff);
+    if (ctx->deep)
+        hipLaunchKernelGGL((trace_kernel<false, false, true>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
+                           queue, ctx->stats, nullptr, nullptr, nullptr, state);
+    else
+        hipLaunchKernelGGL((trace_kernel<false, false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
+                           queue, ctx->stats, nullptr, nullptr, nullptr, state);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!async) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return CRT_OK;
 }
 
 int crt_last_kernel_ms(crt_ctx* ctx, float* ms) {

@@ -38,6 +38,10 @@ class Context:
     def render_pass(self, pass_id, samples, stream=None, wait=True):
         self._check(capi.lib().crt_render_pass(self._h, pass_id, samples, C.c_void_p(stream or 0), 0 if wait else 1))
 
+    def render_pass_noalloc(self, pass_id, samples, stream=None, wait=True):
+        """render_pass on the library's static device workspace: makes no device allocation."""
+        self._check(capi.lib().crt_render_pass_noalloc(self._h, pass_id, samples, C.c_void_p(stream or 0), 0 if wait else 1))
+
     def render_pass_counted(self, pass_id, samples):
         self._check(capi.lib().crt_render_pass_counted(self._h, pass_id, samples))
 

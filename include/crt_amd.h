@@ -214,6 +214,21 @@ int crt_clear_async(crt_ctx* ctx, void* stream);
  * call returns after the kernel has been enqueued when async != 0. */
 int crt_render_pass(crt_ctx* ctx, int pass_id, int samples, void* stream, int async);
 
+/* crt_render_pass for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * It has no counterpart in the reference.  Same arguments, same accumulators
+ * and ray counters as crt_render_pass, bit for bit; the kernel's workspace
+ * (pixel-queue counter, sequence-jump matrix, per-lane path state) is a fixed
+ * 32 MiB array inside the library's code object, one copy per GPU, instead of
+ * buffers from hipMalloc, and the call makes no allocation on the device (a
+ * pass_id > 0 seen for the first time computes its jump matrix on the host).
+ * The grid shrinks to the lanes whose state fits; a scene whose BVH is so deep
+ * that one block's state does not fit fails with CRT_E_LIMIT.  Tiles are
+ * handed out in storage order and no kernel time is recorded.  Every call on
+ * one GPU, from any context, shares that GPU's array: calls that overlap on
+ * one GPU race and must be ordered by the caller. */
+int crt_render_pass_noalloc(crt_ctx* ctx, int pass_id, int samples, void* stream, int async);
+
 /* ConvertColors<<<...>>>(results, out, N, sRGB, pass_mul) (math/color.cu:19-23,
  * launch at renderer/renderer.cu:51).  rgb_out_device is W*H*3 bytes of device
  * memory, or NULL to convert into the context's own buffer. */
