@@ -181,6 +181,7 @@ int validate_desc(crt_ctx* ctx, const crt_scene_desc* d) {
     if (d->env_texture < 0 || (uint32_t)d->env_texture >= d->texture_count) return fail(ctx, CRT_E_INVALID, "environment texture index out of range");
     for (uint32_t i = 0; i < d->texture_count; i++) {
         const crt_texture& t = d->textures[i];
+        if ((t.width == 0) != (t.height == 0)) return fail(ctx, CRT_E_INVALID, "texture with exactly one zero dimension");
         if ((uint64_t)t.width * t.height > 0 && !t.rgb) return fail(ctx, CRT_E_INVALID, "texture without texels");
     }
     for (uint32_t i = 0; i < d->material_count; i++) {
@@ -188,6 +189,8 @@ int validate_desc(crt_ctx* ctx, const crt_scene_desc* d) {
         for (int id : {m.diffuse, m.specular, m.refraction, m.emission})
             if (id < 0 || (uint32_t)id >= d->texture_count) return fail(ctx, CRT_E_INVALID, "material texture index out of range");
     }
+    if (d->light_count && !d->lights) return fail(ctx, CRT_E_INVALID, "light count without a light array");
+    if (d->mesh_count && !d->meshes) return fail(ctx, CRT_E_INVALID, "mesh count without a mesh array");
     for (uint32_t i = 0; i < d->light_count; i++)
         if (d->lights[i].kind < CRT_LIGHT_AMBIENT || d->lights[i].kind > CRT_LIGHT_POINT) return fail(ctx, CRT_E_INVALID, "bad light kind");
     for (uint32_t i = 0; i < d->mesh_count; i++) {
@@ -202,7 +205,18 @@ int validate_desc(crt_ctx* ctx, const crt_scene_desc* d) {
             if (m.nvt && m.ft[k] >= m.nvt) return fail(ctx, CRT_E_INVALID, "mesh texture index out of range");
         }
     }
-    // child counts must describe a depth-first forest that ends exactly at node_count
+    // child counts must describe a depth-first forest that ends exactly at node_count: walking the list with a
+    // stack of "children still to come" must never run past the end and must leave no child outstanding
+    {
+        std::vector<uint32_t> open;
+        for (uint32_t i = 0; i < d->node_count; i++) {
+            while (!open.empty() && open.back() == 0) open.pop_back();
+            if (!open.empty()) open.back()--;
+            if (d->nodes[i].child_count) open.push_back(d->nodes[i].child_count);
+        }
+        while (!open.empty() && open.back() == 0) open.pop_back();
+        if (!open.empty()) return fail(ctx, CRT_E_INVALID, "node child counts run past the end of the node list");
+    }
     for (uint32_t i = 0; i < d->node_count; i++) {
         const crt_node& n = d->nodes[i];
         if (n.object_kind < CRT_OBJ_NONE || n.object_kind > CRT_OBJ_MESH) return fail(ctx, CRT_E_INVALID, "bad object kind");
@@ -224,6 +238,12 @@ void subtree_ends(const crt_scene_desc* d, std::vector<uint32_t>& after) {
         size[i] = total;
         after[i] = (uint32_t)i + total > n ? n : (uint32_t)i + total;
     }
+}
+
+// queue items of the whole image cut into strips of strip_rows rows (padded to whole 8x8 tiles)
+uint64_t partition_items(const DevScene& S, uint32_t strip_rows) {
+    const uint64_t strips = (S.height + strip_rows - 1) / strip_rows;
+    return strips * ((S.width + 7) / 8) * (strip_rows / 8) * 64;
 }
 
 void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_rows) {
@@ -261,22 +281,17 @@ int crt_create(int device, crt_ctx** out) {
     if (device < 0 || device >= count) { crt::set_host_error("device index out of range"); return CRT_E_INVALID; }
     crt_ctx* ctx = new crt_ctx();
     ctx->device = device;
+    // one exit for every failure: crt_destroy releases whatever exists by then
+    auto give_up = [&](const char* msg) { crt_destroy(ctx); crt::set_host_error(msg); return CRT_E_HIP; };
     hipDeviceProp_t prop;
-    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
-        delete ctx; crt::set_host_error("cannot select HIP device"); return CRT_E_HIP;
-    }
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return give_up("cannot select HIP device");
     ctx->num_cus = prop.multiProcessorCount;
-    if (scratch_for_device(device, &ctx->scratch) != hipSuccess) {
-        delete ctx; crt::set_host_error("cannot resolve the static workspace on this device"); return CRT_E_HIP;
-    }
+    if (scratch_for_device(device, &ctx->scratch) != hipSuccess) return give_up("cannot resolve the static workspace on this device");
     if (hipMalloc((void**)&ctx->queue, 256) != hipSuccess || hipMalloc((void**)&ctx->stats, sizeof(DevStats)) != hipSuccess ||
-        hipMemset(ctx->stats, 0, sizeof(DevStats)) != hipSuccess) {
-        delete ctx; crt::set_host_error("cannot allocate context buffers"); return CRT_E_HIP;
-    }
+        hipMemset(ctx->stats, 0, sizeof(DevStats)) != hipSuccess)
+        return give_up("cannot allocate context buffers");
     for (int i = 0; i < crt_ctx::kRing; i++)
-        if (hipEventCreate(&ctx->ev0[i]) != hipSuccess || hipEventCreate(&ctx->ev1[i]) != hipSuccess) {
-            delete ctx; crt::set_host_error("cannot create timing events"); return CRT_E_HIP;
-        }
+        if (hipEventCreate(&ctx->ev0[i]) != hipSuccess || hipEventCreate(&ctx->ev1[i]) != hipSuccess) return give_up("cannot create timing events");
     *out = ctx;
     return CRT_OK;
 }
@@ -537,6 +552,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         ctx->allocs.push_back(ctx->tile_order);
     }
 
+    if (partition_items(S, 16) > 0x7fffffffull) return fail(ctx, CRT_E_LIMIT, "image too large for the pixel queue");
     ctx->have_scene = true;
     set_partition(ctx, 0, 1, 16);
     return CRT_OK;
@@ -546,9 +562,7 @@ int crt_set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t stri
     if (!ctx) return CRT_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
     if (parts == 0 || part >= parts || strip_rows == 0 || strip_rows % 8 != 0) return fail(ctx, CRT_E_INVALID, "bad partition (strip_rows must be a positive multiple of 8)");
-    const uint64_t strips = (ctx->S.height + strip_rows - 1) / strip_rows;
-    const uint64_t items = strips * ((ctx->S.width + 7) / 8) * (strip_rows / 8) * 64;
-    if (items > 0x7fffffffull) return fail(ctx, CRT_E_LIMIT, "image too large for the pixel queue");
+    if (partition_items(ctx->S, strip_rows) > 0x7fffffffull) return fail(ctx, CRT_E_LIMIT, "image too large for the pixel queue");
     set_partition(ctx, part, parts, strip_rows);
     return CRT_OK;
 }
@@ -775,28 +789,31 @@ int crt_primary_hits(crt_ctx* ctx, int pass_id, int32_t* node, int32_t* face, fl
     int rc = get_jump(ctx, pass_id, &jump);
     if (rc) return rc;
     const size_t px = (size_t)ctx->S.width * ctx->S.height;
-    int32_t *d_node = nullptr, *d_face = nullptr;
-    float* d_t = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&d_node, px * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&d_face, px * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&d_t, px * 4));
+    // released on every return path
+    struct Buffers {
+        int32_t *node = nullptr, *face = nullptr;
+        float* t = nullptr;
+        ~Buffers() { if (node) (void)hipFree(node); if (face) (void)hipFree(face); if (t) (void)hipFree(t); }
+    } d;
+    HIP_TRY(ctx, hipMalloc((void**)&d.node, px * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d.face, px * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&d.t, px * 4));
     // pixels this context does not own read as "not traced"
-    HIP_TRY(ctx, hipMemset(d_node, 0xff, px * 4));
-    HIP_TRY(ctx, hipMemset(d_face, 0xff, px * 4));
-    HIP_TRY(ctx, hipMemset(d_t, 0, px * 4));
+    HIP_TRY(ctx, hipMemset(d.node, 0xff, px * 4));
+    HIP_TRY(ctx, hipMemset(d.face, 0xff, px * 4));
+    HIP_TRY(ctx, hipMemset(d.t, 0, px * 4));
     if (ctx->P.total_items) {
         HIP_TRY(ctx, hipMemset(ctx->queue, 0, 4));
         uint32_t grid = (uint32_t)(ctx->num_cus * ctx->blocks_per_cu);
         const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
         if (grid > need) grid = need;
-        launch_trace<false, true>(ctx, grid, nullptr, ctx->P, 1, jump, d_node, d_face, d_t);
+        launch_trace<false, true>(ctx, grid, nullptr, ctx->P, 1, jump, d.node, d.face, d.t);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipDeviceSynchronize());
-    if (node) HIP_TRY(ctx, hipMemcpy(node, d_node, px * 4, hipMemcpyDeviceToHost));
-    if (face) HIP_TRY(ctx, hipMemcpy(face, d_face, px * 4, hipMemcpyDeviceToHost));
-    if (t) HIP_TRY(ctx, hipMemcpy(t, d_t, px * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_node); (void)hipFree(d_face); (void)hipFree(d_t);
+    if (node) HIP_TRY(ctx, hipMemcpy(node, d.node, px * 4, hipMemcpyDeviceToHost));
+    if (face) HIP_TRY(ctx, hipMemcpy(face, d.face, px * 4, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(ctx, hipMemcpy(t, d.t, px * 4, hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
