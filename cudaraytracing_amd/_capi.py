@@ -69,14 +69,14 @@ class BvhArrays(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("closest_rays", "shadow_rays", "paths", "node_box_tests", "node_enters",
                                            "bvh_interior", "bvh_leaves", "tri_tests", "tri_hits", "sphere_tests",
-                                           "plane_tests", "texel_quads")] + [("sched_turns", C.c_uint64 * 8), ("sched_lanes", C.c_uint64 * 8), ("sched_cycles", C.c_uint64 * 8), ("path_cycles", C.c_uint64 * 8), ("scan_checks", C.c_uint64), ("scan_violations", C.c_uint64)]
+                                           "plane_tests", "texel_quads")] + [("sched_turns", C.c_uint64 * 8), ("sched_lanes", C.c_uint64 * 8), ("sched_cycles", C.c_uint64 * 8), ("path_cycles", C.c_uint64 * 8), ("scan_checks", C.c_uint64), ("scan_violations", C.c_uint64), ("errors", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_[:12]}
 
     def schedule(self):
         """Per operation (box, triangle, transform, path, fetch): wave turns and lanes served."""
-        names = ("box", "triangle", "transform", "path", "fetch")
+        names = ("box", "triangle", "transform", "path", "exchange", "fetch")
         return {n: (int(self.sched_turns[i]), int(self.sched_lanes[i]), int(self.sched_cycles[i])) for i, n in enumerate(names)}
 
 
@@ -119,6 +119,7 @@ _PROTOS = {
     "crt_render_pass_counted": (C.c_int, [_VP, C.c_int, C.c_int]),
     "crt_rng_selftest": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "crt_math_selftest": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_uint32, _VP]),
+    "crt_knob_value": (C.c_uint32, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "crt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "crt_kernel_times": (C.c_int, [_VP, _VP, C.c_uint32, C.POINTER(C.c_uint32)]),
 }

@@ -26,7 +26,7 @@ struct crt_ctx {
     std::vector<void*> allocs;                 // everything owned by the current scene
     uint8_t* rgb8 = nullptr;
     uint32_t* queue = nullptr;
-    uint32_t* cold = nullptr;                  // per-thread path state of the trace kernel
+    uint32_t* cold = nullptr;                  // pixel-slot records (and stack overflow columns) of the trace kernel
     uint32_t* tile_cost = nullptr;             // ray queries per tile, measured by the pass in flight
     uint32_t* tile_order = nullptr;            // tiles sorted by the previous pass's cost
     uint32_t tile_capacity = 0;
@@ -257,6 +257,20 @@ void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_r
     P.tile_order = nullptr;
     P.tile_cost = nullptr;
     ctx->order_valid = false;                  // costs of another partition say nothing about this one
+}
+
+// global memory one block of the trace kernel needs: its pixel-slot records and, for deep trees, the stack overflow
+// columns of its traversal threads
+size_t block_state_bytes(const crt_ctx* ctx) {
+    return (size_t)ctx->S.slots * kSlotWords * 4 + (size_t)ctx->S.trav_waves * 64 * 2 * ctx->stack_overflow * 4;
+}
+
+// blocks to launch: what stays resident, but no more than gives every traversal lane a pixel
+uint32_t trace_grid(const crt_ctx* ctx, int per_cu) {
+    uint32_t grid = (uint32_t)(ctx->num_cus * per_cu);
+    const uint32_t lanes = ctx->S.trav_waves * 64;
+    const uint32_t need = (ctx->P.total_items + lanes - 1) / lanes;
+    return grid > need ? need : grid;
 }
 
 template <bool kCount, bool kPrimary>
@@ -495,11 +509,18 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         // profiling only: the counted build then scans by the mask too (its node counters no longer match the reference's)
         if (const char* e = getenv("CRT_COUNTED_BY_MASK")) if (atoi(e) != 0 && S.scan_mask) S.scan_mask = 3;
     }
-    // measured optima: 12 / 6 / 24 on the benchmark frame; a deep BVH (the ten-million-triangle scene) prefers 16
-    S.sched_box_min = ctx->deep ? 16 : 12; S.sched_special_min = 6; S.sched_heavy_min = 24;
-    if (const char* e = getenv("CRT_SCHED_BOX_MIN")) S.sched_box_min = (uint32_t)atoi(e);
-    if (const char* e = getenv("CRT_SCHED_SPECIAL_MIN")) S.sched_special_min = (uint32_t)atoi(e);
-    if (const char* e = getenv("CRT_SCHED_HEAVY_MIN")) S.sched_heavy_min = (uint32_t)atoi(e);
+    // Scheduler and block-shape parameters (defaults measured on the benchmark frame; a deep BVH, the ten-million-
+    // triangle scene, prefers a higher box threshold).  Environment overrides outside the stated range are ignored.
+    S.sched_box_min = crt::knob_value(getenv("CRT_SCHED_BOX_MIN"), 20, 1, 64);
+    S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
+    S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), 8, 1, 64);
+    S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 3 / 4, 1, CRT_BLOCK / 64 - 1);
+    S.slots = crt::knob_value(getenv("CRT_SLOTS"), 2 * S.trav_waves * 64 < kQueueSize ? 2 * S.trav_waves * 64 : kQueueSize, 64, kQueueSize);
+    S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
+    S.serve_low_water = crt::knob_value(getenv("CRT_SERVE_LOW_WATER"), 64, 0, kQueueSize);
+    S.serve_patience = crt::knob_value(getenv("CRT_SERVE_PATIENCE"), 64, 0, 1u << 20);
+    S.serve_priority = crt::knob_value(getenv("CRT_SERVE_PRIORITY"), 1, 0, 1);
+    S.watchdog_ticks = 100000000ull * crt::knob_value(getenv("CRT_WATCHDOG_SECONDS"), 30, 1, 3600);
     { const char* e = getenv("CRT_NO_BALANCE"); ctx->no_balance = e && atoi(e) != 0; }
     if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
         (rc = upload(ctx, attrs, &S.attrs)) || (rc = upload(ctx, materials, &S.materials)) ||
@@ -519,9 +540,10 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     HIP_TRY(ctx, hipMemset(ctx->rgb8, 0, px * 3));
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
 
-    // two LDS arrays (node reference, entry distance) of stack_entries x 256 words
-    ctx->lds_bytes = (size_t)S.stack_entries * CRT_BLOCK * 4 * 2;
-    if (ctx->lds_bytes > 160 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");
+    // two LDS arrays (node reference, entry distance) of stack_entries words per traversal thread
+    const uint32_t trav_threads = S.trav_waves * 64;
+    ctx->lds_bytes = (size_t)S.stack_entries * trav_threads * 4 * 2;
+    if (ctx->lds_bytes > 140 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");
     if (ctx->deep) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
@@ -539,8 +561,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     if (ctx->blocks_per_cu_counted < 1) ctx->blocks_per_cu_counted = 1;
     {
         const int per_cu = ctx->blocks_per_cu > ctx->blocks_per_cu_counted ? ctx->blocks_per_cu : ctx->blocks_per_cu_counted;
-        const size_t threads = (size_t)ctx->num_cus * per_cu * CRT_BLOCK;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->cold, threads * (C_WORDS + 2ull * ctx->stack_overflow) * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->cold, (size_t)ctx->num_cus * per_cu * block_state_bytes(ctx)));
         ctx->allocs.push_back(ctx->cold);
     }
     {
@@ -597,10 +618,7 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     if (rc) return rc;
     if (ctx->P.total_items == 0) return CRT_OK;
     HIP_TRY(ctx, hipMemsetAsync(ctx->queue, 0, 4, stream));
-    const int per_cu = counted ? ctx->blocks_per_cu_counted : ctx->blocks_per_cu;
-    uint32_t grid = (uint32_t)(ctx->num_cus * per_cu);
-    const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
-    if (grid > need) grid = need;
+    const uint32_t grid = trace_grid(ctx, counted ? ctx->blocks_per_cu_counted : ctx->blocks_per_cu);
     // Load balance: this pass measures a cost per tile and the next one hands tiles out costliest first.
     // (Passes of one context are expected on one stream, or ordered by the caller.)
     const uint32_t tiles = ctx->P.total_items >> 6;
@@ -644,15 +662,13 @@ int crt_render_pass_noalloc(crt_ctx* ctx, int pass_id, int samples, void* stream
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->P.total_items == 0) return CRT_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    // the grid is cut down to the lanes whose path state fits the workspace
-    const size_t lane_bytes = (C_WORDS + 2ull * ctx->stack_overflow) * 4;
-    const size_t blocks_fit = (kScratchBytes - kScratchStateOff) / (lane_bytes * CRT_BLOCK);
+    // the grid is cut down to the blocks whose pixel slots fit the workspace
+    const size_t block_bytes = block_state_bytes(ctx);
+    const size_t blocks_fit = (kScratchBytes - kScratchStateOff) / block_bytes;
     if (blocks_fit < 1)
-        return fail(ctx, CRT_E_LIMIT, "scene needs " + std::to_string(lane_bytes * CRT_BLOCK) + " bytes of path state per block, the static workspace holds " +
+        return fail(ctx, CRT_E_LIMIT, "scene needs " + std::to_string(block_bytes) + " bytes of path state per block, the static workspace holds " +
                                       std::to_string(kScratchBytes - kScratchStateOff));
-    uint32_t grid = (uint32_t)(ctx->num_cus * ctx->blocks_per_cu);
-    const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
-    if (grid > need) grid = need;
+    uint32_t grid = trace_grid(ctx, ctx->blocks_per_cu);
     if (grid > blocks_fit) grid = (uint32_t)blocks_fit;
     unsigned char* ws = ctx->scratch;
     const uint32_t* jump = nullptr;
@@ -804,9 +820,7 @@ int crt_primary_hits(crt_ctx* ctx, int pass_id, int32_t* node, int32_t* face, fl
     HIP_TRY(ctx, hipMemset(d.t, 0, px * 4));
     if (ctx->P.total_items) {
         HIP_TRY(ctx, hipMemset(ctx->queue, 0, 4));
-        uint32_t grid = (uint32_t)(ctx->num_cus * ctx->blocks_per_cu);
-        const uint32_t need = (ctx->P.total_items + CRT_BLOCK - 1) / CRT_BLOCK;
-        if (grid > need) grid = need;
+        const uint32_t grid = trace_grid(ctx, ctx->blocks_per_cu);
         launch_trace<false, true>(ctx, grid, nullptr, ctx->P, 1, jump, d.node, d.face, d.t);
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -828,6 +842,8 @@ int crt_get_stats(crt_ctx* ctx, crt_stats* out) {
     out->sphere_tests = s.sphere_tests; out->plane_tests = s.plane_tests; out->texel_quads = s.texel_quads;
     for (int k = 0; k < 8; k++) { out->sched_turns[k] = s.sched_turns[k]; out->sched_lanes[k] = s.sched_lanes[k]; out->sched_cycles[k] = s.sched_cycles[k]; out->path_cycles[k] = s.path_cycles[k]; }
     out->scan_checks = s.scan_checks; out->scan_violations = s.scan_violations;
+    out->errors = s.errors;
+    if (s.errors) return fail(ctx, CRT_E_HIP, "the trace kernel reported " + std::to_string(s.errors) + " queue protocol error(s): the image is incomplete");
     return CRT_OK;
 }
 

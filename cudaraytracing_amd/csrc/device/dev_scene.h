@@ -114,7 +114,15 @@ struct DevScene {
     uint32_t stack_entries;          // LDS stack slots per lane (deeper entries overflow into the side buffer)
     uint32_t sched_box_min;          // box steps run unconditionally while this many lanes of a wave want one
     uint32_t sched_special_min;      // a triangle / transform turn runs once this many lanes wait for it
-    uint32_t sched_heavy_min;        // a path / fetch turn outvoting the box lanes needs this many lanes
+    uint32_t sched_exchange_min;     // an exchange turn (post results, take new queries) runs once this many lanes want one
+    // block shape of the trace kernel: the first trav_waves waves of a block run ray queries, the others shade
+    uint32_t trav_waves;
+    uint32_t slots;                  // pixel slots per block (<= 1024)
+    uint32_t serve_batch_min;        // a shading wave waits for this many slots ...
+    uint32_t serve_low_water;        // ... while at least this many queries are ready for the traversal lanes ...
+    uint32_t serve_patience;         // ... but for no more than this many polls
+    uint32_t serve_priority;         // shading waves run at raised instruction-issue priority
+    unsigned long long watchdog_ticks;   // 100 MHz ticks a wave may find nothing to do before it reports a protocol error
     // Candidate mask of the scene-node scan (see scan_candidates in kernels.hip).  drift_rel / drift_abs bound how
     // far a ray can move over one whole query through the ToLocal / FromLocal round trips of the nodes it enters:
     // |pos' - pos| <= drift_rel * max|pos| + drift_abs, |dir' - dir| <= drift_rel * max|dir| (per component).
@@ -157,6 +165,7 @@ struct DevStats {
     unsigned long long sched_turns[8], sched_lanes[8], sched_cycles[8];
     unsigned long long path_cycles[8];
     unsigned long long scan_checks, scan_violations;   // counted build: box hits of the scan checked against the candidate mask
+    unsigned long long errors;                         // waves that gave up waiting on the block's queues (must stay 0)
 };
 
 }  // namespace crt

@@ -35,7 +35,9 @@
 
 namespace crt {
 
-#define CRT_BLOCK 256
+#ifndef CRT_BLOCK
+#define CRT_BLOCK 512                // threads of a trace-kernel block (the element-wise kernels use it too)
+#endif
 #ifndef CRT_WAVES_PER_SIMD
 #define CRT_WAVES_PER_SIMD 4        // register budget 128: the best measured balance of occupancy and spills
 #endif
@@ -99,7 +101,7 @@ DEV void rng_init(Rng& s, uint32_t seed_lo, const uint32_t* __restrict__ jump) {
 struct Tally {
     uint32_t closest_rays, shadow_rays, paths;
     uint32_t node_box_tests, node_enters, bvh_interior, bvh_leaves, tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
-    uint32_t turns[8], lanes[8];
+    uint32_t turns[8], lanes[8];     // per operation: 0 box, 1 triangle, 2 transform, 3 shading, 4 exchange, 5 pixel fetch
     uint32_t scan_checks, scan_violations;
     unsigned long long cycles[8];
 };
@@ -335,22 +337,28 @@ DEV unsigned long long scan_candidates(const DevScene& S, const BoxPair* __restr
     return ((unsigned long long)hi << 32) | lo;
 }
 
+DEV void acc_add(float* __restrict__ p, f3 v) {
+    p[0] += v.x; p[1] += v.y; p[2] += v.z;
+}
+
 // ------------------------------------------------------------------ per-lane state
-// Operation a lane needs next.
+// Operation a traversal lane needs next.
 //   BOX    slab-test one box-pair record (scene-node scan or BVH interior node)
 //   LEAF   test the next one or two triangles of the pending leaf
 //   XFORM  enter a scene node (world -> local, sphere / plane test or BVH root) or leave a mesh
-//   PATH   a query has ended or a pixel has just been fetched: shade / add the light sample /
-//          start the next query or the next path
-//   FETCH  the pixel is finished: the next PATH turn starts by taking a new one from the queue
-enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_XFORM = 2, S_PATH = 3, S_FETCH = 4, S_DONE = 5 };
+//   POST   the query has ended: its result has to be handed to the shading waves
+//   IDLE   the lane has no query: it takes the next one from the block's ray queue
+enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_XFORM = 2, S_POST = 3, S_IDLE = 4 };
 enum : uint32_t { H_NONE = 0, H_SPHERE = 1, H_PLANE = 2, H_MESH = 3 };
-enum : uint32_t { PK_NEW_PATH = 0, PK_CLOSEST_DONE = 1, PK_SHADOW_CLEAR = 2, PK_SHADOW_BLOCKED = 3 };
+// why a slot is in the shading queue
+enum : uint32_t { PK_NEW_PATH = 0, PK_CLOSEST_DONE = 1, PK_SHADOW_CLEAR = 2, PK_SHADOW_BLOCKED = 3, PK_FETCH = 4 };
+// what a shading turn decided for a slot
+enum : uint32_t { R_NONE = 0, R_RAY = 1, R_REFETCH = 2, R_RETIRE = 3 };
 constexpr uint32_t kPendExit = 0x20000000u;     // XFORM: leave the mesh of node `entered`
 
 struct Lane {
-    uint32_t pI;                    // pixel being rendered
-    uint32_t pk;                    // why the lane is in PATH
+    uint32_t slot;                  // pixel slot whose query this lane is running
+    uint32_t pk;                    // how the query ended
     // current ray query (closest hit or shadow)
     // Ray in the space it is currently in, kept as (position, direction) pairs per axis so that transforms and
     // the triangle test run on two-float packed instructions; and 1 / direction.
@@ -377,42 +385,120 @@ struct Lane {
     bool h_front;
 };
 
-// Path state that only the PATH operation touches lives in global memory (one column per thread,
-// field-major so that a wave's access to one field is contiguous) instead of being carried in
-// registers through every turn of the scheduler loop: random state, throughput, view vector, the
-// continuation ray and the pending light sample of a path whose shadow query is running.
-enum : uint32_t {
-    C_RNG = 0,        // 6 words
-    C_CONTRIB = 6,    // 3
-    C_V = 9,          // 3
-    C_NDIR = 12,      // 3
-    C_NEE = 15,       // 3
-    C_SAMPLE = 18, C_SEGMENTS = 19, C_FLAGS = 20,
-    C_TILE = 21,      // storage-order index of the pixel's tile
-    C_COST = 22,      // ray queries of this pixel so far
-    C_WORDS = 23
+// ------------------------------------------------------------------ pixel slots and the block's two queues
+// A block owns S.slots pixel slots.  A slot holds one pixel at a time and everything that pixel carries from one
+// ray query to the next, as one 256-byte record in global memory:
+//   words  0..15  RAY   the query to run: written by a shading lane, read by the traversal lane that takes it
+//   words 16..31  HIT   how the query ended: written by that traversal lane, read by a shading lane
+//   words 32..59  PATH  random stream (6), throughput (3), view vector (3), sample, segment, cost, pixel; then what is
+//                       parked while a shadow query runs (continuation direction, flags, light sample, hit
+//                       position) and the pixel's tile: only the shading waves touch it
+// Slots, not lanes, own pixels: a traversal lane that finishes a query posts the slot to the block's shading queue
+// and takes whatever query is ready next, a shading lane does the opposite, so both kinds of wave run with their
+// lanes full while any one pixel still sees its operations in the reference's order.  Both queues are rings of
+// slot numbers in LDS; an entry carries the lap number of its position, so a consumer that has claimed a position
+// knows when the producer's write has landed without a second counter.
+constexpr uint32_t kQueueLog = 11, kQueueSize = 1u << kQueueLog;      // ring positions; slots per block <= kQueueSize
+constexpr uint32_t kSlotWords = 64;
+constexpr uint32_t kRecRay = 0, kRecHit = 16, kRecPath = 32;
+constexpr uint32_t kMaxWaves = 16;
+
+struct BlockCtl {
+    uint32_t shade_head, shade_tail;    // slots waiting for a shading lane
+    uint32_t ray_head, ray_tail;        // slots whose next query waits for a traversal lane
+    uint32_t live;                      // slots that still have a pixel or may get one
+    uint32_t abort;                     // a wave gave up waiting (a protocol error): every wave leaves
 };
 
-DEV void acc_add(float* __restrict__ p, f3 v) {
-    p[0] += v.x; p[1] += v.y; p[2] += v.z;
+DEV uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Every lane with `want` appends its slot.  The caller has made the slot's record visible to the block
+// (release fence) before the call.
+DEV void queue_push(uint32_t* tail, uint32_t* ring, bool want, uint32_t slot) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if (want && lane_rank(m) == 0) base = atomicAdd(tail, (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    if (want) {
+        const uint32_t idx = base + lane_rank(m);
+        lds_st(&ring[idx & (kQueueSize - 1u)], (((idx >> kQueueLog) + 1u) << kQueueLog) | slot);
+    }
 }
 
-// ------------------------------------------------------------------ the scheduled path tracer
-// kDeep: the BVH is deeper than the LDS stack; entries above S.stack_entries live in a per-thread overflow
-// area of the side buffer (rarely reached: a ray's stack is usually a fraction of the tree depth).
+// The lanes with `want` claim up to that many entries, but none unless at least min_take are there; a lane that
+// got one returns true and its slot.  One compare-and-swap per wave; when another wave wins it the call
+// takes nothing and the caller comes back later.
+DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const uint32_t* ring, bool want, uint32_t min_take, uint32_t slot_limit,
+                   uint32_t& slot, uint32_t* abort_flag) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return false;
+    const uint32_t nw = (uint32_t)__popcll(m);
+    uint32_t h = 0, k = 0;
+    if (want && lane_rank(m) == 0) {
+        h = lds_ld(head);
+        const uint32_t avail = lds_ld(tail) - h;
+        k = avail < nw ? avail : nw;
+        if (k < min_take || avail > kQueueSize) k = 0;
+        if (k && atomicCAS(head, h, h + k) != h) k = 0;
+    }
+    const int leader = __ffsll((long long)m) - 1;
+    h = __shfl(h, leader, 64);
+    k = __shfl(k, leader, 64);
+    const uint32_t r = lane_rank(m);
+    const bool got = want && r < k;
+    if (got) {
+        const uint32_t idx = h + r;
+        const uint32_t tag = ((idx >> kQueueLog) + 1u) & ((1u << (32 - kQueueLog)) - 1u);
+        uint32_t e = lds_ld(&ring[idx & (kQueueSize - 1u)]), spins = 0;
+        // the producer reserved this position before the count said so; its write is a few instructions away
+        while ((e >> kQueueLog) != tag) {
+            if (++spins > (1u << 22)) { lds_st(abort_flag, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+            e = lds_ld(&ring[idx & (kQueueSize - 1u)]);
+        }
+        slot = e & (kQueueSize - 1u);
+        if (slot >= slot_limit) slot = slot_limit - 1u;      // only after an abort: stay inside the block's records
+    }
+    return got;
+}
+
+// ------------------------------------------------------------------ the path tracer
+// One launch runs every pixel of the partition.  The waves of a block have fixed roles: the first S.trav_waves
+// run ray queries (BOX / LEAF / XFORM operations, voted per turn), the others run everything between two
+// queries of a pixel (shading, light and BSDF sampling, new camera rays, taking the next pixel from the global
+// queue).  kDeep: the BVH is deeper than the LDS stack; entries above S.stack_entries live in a per-thread
+// overflow area of the side buffer (rarely reached: a ray's stack is usually a fraction of the tree depth).
 template <bool kCount, bool kPrimary, bool kDeep>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(DevScene S, DevPartition P, int samples,
                                                              const uint32_t* __restrict__ jump,
                                                              uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
                                                              int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
-                                                             float* __restrict__ out_t, uint32_t* __restrict__ cold) {
+                                                             float* __restrict__ out_t, uint32_t* slot_mem) {
     extern __shared__ uint32_t lds[];
-    __shared__ unsigned long long sect_clock[4], path_sections[32], wave_clock[8];      // counted build only
-    if (kCount) { if (threadIdx.x < 32) path_sections[threadIdx.x] = 0; __syncthreads(); }
-    uint32_t* __restrict__ stack_ref = lds;
-    float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * CRT_BLOCK);
-    const uint32_t lds_entries = S.stack_entries;
+    __shared__ BlockCtl ctl;
+    __shared__ uint32_t shade_ring[kQueueSize], ray_ring[kQueueSize];
+    __shared__ unsigned long long sect_clock[kMaxWaves], path_sections[kMaxWaves * 8], wave_clock[kMaxWaves * 2];      // counted build only
     const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6;
+    const uint32_t trav_threads = S.trav_waves * 64u;
+    const uint32_t n_slots = S.slots;
+    uint32_t* const block_slots = slot_mem + (size_t)blockIdx.x * n_slots * kSlotWords;
+    auto slot_rec = [&](uint32_t slot) -> uint32_t* { return block_slots + (size_t)slot * kSlotWords; };
+
+    // ---- block set-up: every slot starts in the shading queue asking for a pixel
+    if (kCount) for (uint32_t i = tid; i < kMaxWaves * 8; i += CRT_BLOCK) path_sections[i] = 0;
+    for (uint32_t i = tid; i < kQueueSize; i += CRT_BLOCK) {
+        ray_ring[i] = 0;
+        shade_ring[i] = i < n_slots ? ((1u << kQueueLog) | i) : 0u;
+    }
+    for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
+    if (tid == 0) { ctl.shade_head = 0; ctl.shade_tail = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
     const BoxPair* __restrict__ pairs = S.pairs;
     const TriRec* __restrict__ tris = S.tris;
     const uint32_t node_count = S.node_count;
@@ -421,666 +507,817 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const bool by_mask = S.scan_mask != 0 && (!kCount || (S.scan_mask & 2u) != 0);      // bit 1: profiling, the counted build follows the mask too
 
     Tally tally = {};
-    // counted build: when the wave started / first found the queue dry (per wave, in LDS)
-    if (kCount && (threadIdx.x & 63u) == 0) { wave_clock[(threadIdx.x >> 6) * 2] = __builtin_amdgcn_s_memtime(); wave_clock[(threadIdx.x >> 6) * 2 + 1] = 0; }
-    const float F_PI = 3.14159265358979323846f;
-    const float OVERPI = (float)(1.0f / 3.14159265358979323846);
-    const float inv_samples = 1.0f / (float)samples;
-
-    Lane L = {};
-    uint32_t state = S_FETCH;
-    bool queue_empty = false;
-    const uint32_t cold_stride = gridDim.x * CRT_BLOCK;
-    uint32_t* __restrict__ my_cold = cold + (blockIdx.x * CRT_BLOCK + tid);
-    auto cold_ld = [&](uint32_t f) -> uint32_t { return my_cold[(size_t)f * cold_stride]; };
-    auto cold_st = [&](uint32_t f, uint32_t v) { my_cold[(size_t)f * cold_stride] = v; };
-    auto cold_ld3 = [&](uint32_t f) -> f3 { return mk3(__uint_as_float(cold_ld(f)), __uint_as_float(cold_ld(f + 1)), __uint_as_float(cold_ld(f + 2))); };
-    auto cold_st3 = [&](uint32_t f, f3 v) { cold_st(f, __float_as_uint(v.x)); cold_st(f + 1, __float_as_uint(v.y)); cold_st(f + 2, __float_as_uint(v.z)); };
-
-    // traversal stack: LDS, with the overflow area behind the path state in the side buffer for deep trees
-    auto stack_put = [&](uint32_t slot, uint32_t ref, float t) {
-        if (!kDeep || slot < lds_entries) { stack_ref[slot * CRT_BLOCK + tid] = ref; stack_t[slot * CRT_BLOCK + tid] = t; }
-        else { cold_st(C_WORDS + 2 * (slot - lds_entries), ref); cold_st(C_WORDS + 2 * (slot - lds_entries) + 1, __float_as_uint(t)); }
-    };
-    auto stack_get = [&](uint32_t slot, uint32_t& ref, float& t) {
-        if (!kDeep || slot < lds_entries) { ref = stack_ref[slot * CRT_BLOCK + tid]; t = stack_t[slot * CRT_BLOCK + tid]; }
-        else { ref = cold_ld(C_WORDS + 2 * (slot - lds_entries)); t = __uint_as_float(cold_ld(C_WORDS + 2 * (slot - lds_entries) + 1)); }
-    };
-
-    // the query has run out of scene nodes
-    auto query_done = [&]() -> uint32_t { L.pk = L.shadow ? PK_SHADOW_CLEAR : PK_CLOSEST_DONE; return S_PATH; };
-    auto shadow_blocked = [&]() -> uint32_t { L.pk = PK_SHADOW_BLOCKED; return S_PATH; };
-    auto first_candidate = [&]() -> uint32_t { return L.mask ? (uint32_t)__ffsll((long long)L.mask) - 1u : node_count; };
-    auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_BOX : query_done(); };
-
-    // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
-    // (MeshObject::Traverse / TraverseShadow loop heads, scene/objects.cu:184-196, 231-242)
-    auto resolve = [&](bool have_next, uint32_t next_ref, float next_t) -> uint32_t {
-        for (;;) {
-            if (!have_next) {
-                if (L.sp == 0) { L.pend = kPendExit; return S_XFORM; }
-                L.sp--;
-                stack_get(L.sp, next_ref, next_t);
-            }
-            have_next = false;
-            if (!L.shadow && L.hz < next_t) continue;
-            if (!ref_is_leaf(next_ref)) { L.cur = next_ref; return S_BOX; }
-            TALLY(bvh_leaves);
-            if (leaf_count(next_ref) == 0) continue;
-            L.pend = next_ref;
-            return S_LEAF;
+    // counted build: when the wave started / first found the pixel queue dry (per wave, in LDS)
+    if (kCount && (tid & 63u) == 0) { wave_clock[wave * 2] = __builtin_amdgcn_s_memtime(); wave_clock[wave * 2 + 1] = 0; }
+    // a wave that finds nothing to do for this long (100 MHz ticks) reports a protocol error instead of waiting on
+    auto now = []() -> unsigned long long { return __builtin_amdgcn_s_memrealtime(); };
+    unsigned long long idle_since = 0;
+    uint32_t idle_polls = 0;
+    auto idle_wait = [&]() -> bool {       // false: leave the kernel
+        if (lds_ld(&ctl.live) == 0 || lds_ld(&ctl.abort) != 0) return false;
+        if (idle_polls == 0) idle_since = now();
+        if ((++idle_polls & 255u) == 0 && now() - idle_since > S.watchdog_ticks) {
+            lds_st(&ctl.abort, 1u);
+            if ((tid & 63u) == 0) atomicAdd(&stats->errors, 1ull);
+            return false;
         }
+        __builtin_amdgcn_s_sleep(8);
+        return true;
     };
 
-    // ---- BOX: one box-pair record, two slab tests: scene-node scan (trace.cu:51-68, 166-193) or
-    // BVH interior node (objects.cu:198-218, 244-264)
-    auto op_box = [&]() -> uint32_t {
-        const uint32_t rec_idx = L.trav ? L.cur : L.node;
-        const float4* rp = reinterpret_cast<const float4*>(pairs + rec_idx);
-        const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-        const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
-        float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
-        float dA, dB;
-        const bool hitA = slab(f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, L.qpos(), L.qinv, L.limit, dA);
-        const bool hitB = slab(f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, L.qpos(), L.qinv, L.limit, dB);
-        if (hitA) tA = dA;
-        if (hitB) tB = dB;
-        if (L.trav) {
-            TALLY(bvh_interior);
-            // both children go on the stack, far one first (objects.cu:216-218); when neither box is hit the
-            // slot above the top is written and left unused, so one copy of the pop loop serves both cases
-            const bool any = hitA || hitB;
-            const bool a_near = tA <= tB;
-            stack_put(L.sp, a_near ? ref_b : ref_a, fmaxf(tA, tB));
-            L.sp += any ? 1u : 0u;
-            return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
-        }
-        // scan: node `node` is half A, node + 1 is half B.  Closest hit enters a node whose box is
-        // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
-        // subtree of a node with an object whose box it misses (trace.cu:171-185).
-        // (The half after the last node of an odd list is a dummy without an object and with an empty box.)
-        const uint32_t kind_a = node_ref_kind(ref_a), kind_b = node_ref_kind(ref_b);
-        const uint32_t after_a = node_ref_after(ref_a), after_b = node_ref_after(ref_b);
-        const bool sh = L.shadow;
-        if (by_mask) {
-            // Scan by candidates: half A is the lowest candidate, half B is looked at when it is one too.  Nodes in
-            // between were certain misses; a candidate object node that a shadow ray misses takes its subtree along.
-            const uint32_t i = L.node;
-            const bool enter_a = hitA & (sh | (tA < L.hz));
-            unsigned long long m = L.mask & ~(1ull << i);
-            if (sh & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << i) - 1ull);
-            const bool cand_b = !enter_a & (i < 63u) & (((m >> ((i + 1u) & 63u)) & 1ull) != 0);
-            const bool enter_b = cand_b & hitB & (sh | (tB < L.hz));
-            if (cand_b) {
-                m &= ~(2ull << i);
-                if (sh & !hitB) m &= ~(((1ull << (after_b & 63u)) - 1ull) | (after_b >= 64u ? ~0ull : 0ull)) | ((4ull << i) - 1ull);
+    if (wave < S.trav_waves) {
+        // =====================================================================================================
+        // traversal waves
+        // =====================================================================================================
+        uint32_t* __restrict__ stack_ref = lds;
+        float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * trav_threads);
+        const uint32_t lds_entries = S.stack_entries;
+        // overflow of the traversal stack (deep trees): behind the slot records, one column per traversal thread
+        uint32_t* const my_overflow = slot_mem + (size_t)gridDim.x * n_slots * kSlotWords + ((size_t)blockIdx.x * trav_threads + tid);
+        const size_t overflow_stride = (size_t)gridDim.x * trav_threads;
+
+        Lane L = {};
+        uint32_t state = S_IDLE;
+
+        auto stack_put = [&](uint32_t slot, uint32_t ref, float t) {
+            if (!kDeep || slot < lds_entries) { stack_ref[slot * trav_threads + tid] = ref; stack_t[slot * trav_threads + tid] = t; }
+            else { my_overflow[(size_t)(2 * (slot - lds_entries)) * overflow_stride] = ref; my_overflow[(size_t)(2 * (slot - lds_entries) + 1) * overflow_stride] = __float_as_uint(t); }
+        };
+        auto stack_get = [&](uint32_t slot, uint32_t& ref, float& t) {
+            if (!kDeep || slot < lds_entries) { ref = stack_ref[slot * trav_threads + tid]; t = stack_t[slot * trav_threads + tid]; }
+            else { ref = my_overflow[(size_t)(2 * (slot - lds_entries)) * overflow_stride]; t = __uint_as_float(my_overflow[(size_t)(2 * (slot - lds_entries) + 1) * overflow_stride]); }
+        };
+
+        // the query has run out of scene nodes
+        auto query_done = [&]() -> uint32_t { L.pk = L.shadow ? PK_SHADOW_CLEAR : PK_CLOSEST_DONE; return S_POST; };
+        auto shadow_blocked = [&]() -> uint32_t { L.pk = PK_SHADOW_BLOCKED; return S_POST; };
+        auto first_candidate = [&]() -> uint32_t { return L.mask ? (uint32_t)__ffsll((long long)L.mask) - 1u : node_count; };
+        auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_BOX : query_done(); };
+
+        // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
+        // (MeshObject::Traverse / TraverseShadow loop heads, scene/objects.cu:184-196, 231-242)
+        auto resolve = [&](bool have_next, uint32_t next_ref, float next_t) -> uint32_t {
+            for (;;) {
+                if (!have_next) {
+                    if (L.sp == 0) { L.pend = kPendExit; return S_XFORM; }
+                    L.sp--;
+                    stack_get(L.sp, next_ref, next_t);
+                }
+                have_next = false;
+                if (!L.shadow && L.hz < next_t) continue;
+                if (!ref_is_leaf(next_ref)) { L.cur = next_ref; return S_BOX; }
+                TALLY(bvh_leaves);
+                if (leaf_count(next_ref) == 0) continue;
+                L.pend = next_ref;
+                return S_LEAF;
             }
-            L.mask = m;
+        };
+
+        // ---- BOX: one box-pair record, two slab tests: scene-node scan (trace.cu:51-68, 166-193) or
+        // BVH interior node (objects.cu:198-218, 244-264)
+        auto op_box = [&]() -> uint32_t {
+            const uint32_t rec_idx = L.trav ? L.cur : L.node;
+            const float4* rp = reinterpret_cast<const float4*>(pairs + rec_idx);
+            const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
+            float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
+            float dA, dB;
+            const bool hitA = slab(f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, L.qpos(), L.qinv, L.limit, dA);
+            const bool hitB = slab(f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, L.qpos(), L.qinv, L.limit, dB);
+            if (hitA) tA = dA;
+            if (hitB) tB = dB;
+            if (L.trav) {
+                TALLY(bvh_interior);
+                // both children go on the stack, far one first (objects.cu:216-218); when neither box is hit the
+                // slot above the top is written and left unused, so one copy of the pop loop serves both cases
+                const bool any = hitA || hitB;
+                const bool a_near = tA <= tB;
+                stack_put(L.sp, a_near ? ref_b : ref_a, fmaxf(tA, tB));
+                L.sp += any ? 1u : 0u;
+                return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
+            }
+            // scan: node `node` is half A, node + 1 is half B.  Closest hit enters a node whose box is
+            // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
+            // subtree of a node with an object whose box it misses (trace.cu:171-185).
+            // (The half after the last node of an odd list is a dummy without an object and with an empty box.)
+            const uint32_t kind_a = node_ref_kind(ref_a), kind_b = node_ref_kind(ref_b);
+            const uint32_t after_a = node_ref_after(ref_a), after_b = node_ref_after(ref_b);
+            const bool sh = L.shadow;
+            if (by_mask) {
+                // Scan by candidates: half A is the lowest candidate, half B is looked at when it is one too.  Nodes in
+                // between were certain misses; a candidate object node that a shadow ray misses takes its subtree along.
+                const uint32_t i = L.node;
+                const bool enter_a = hitA & (sh | (tA < L.hz));
+                unsigned long long m = L.mask & ~(1ull << i);
+                if (sh & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << i) - 1ull);
+                const bool cand_b = !enter_a & (i < 63u) & (((m >> ((i + 1u) & 63u)) & 1ull) != 0);
+                const bool enter_b = cand_b & hitB & (sh | (tB < L.hz));
+                if (cand_b) {
+                    m &= ~(2ull << i);
+                    if (sh & !hitB) m &= ~(((1ull << (after_b & 63u)) - 1ull) | (after_b >= 64u ? ~0ull : 0ull)) | ((4ull << i) - 1ull);
+                }
+                L.mask = m;
+                if (enter_a | enter_b) {
+                    L.pend = enter_a ? (i | (kind_a << 30)) : ((i + 1u) | (kind_b << 30));
+                    return S_XFORM;
+                }
+                L.node = first_candidate();
+                return after_scan();
+            }
+            const bool obj_a = kind_a != CRT_OBJ_NONE, obj_b = kind_b != CRT_OBJ_NONE;
+            const bool enter_a = obj_a & hitA & (sh | (tA < L.hz));
+            const bool jump_a = sh & obj_a & (after_a != L.node + 1);            // shadow ray past a missed subtree
+            const bool look_b = !(enter_a | jump_a);
+            const bool enter_b = look_b & obj_b & hitB & (sh | (tB < L.hz));
+            if (kCount) {
+                tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b & obj_b) ? 1u : 0u);
+                // every box the full scan finds hit must be a candidate of the mask the plain kernels scan by
+                if (S.scan_mask) {
+                    const bool chk_a = obj_a & hitA, chk_b = look_b & obj_b & hitB;
+                    tally.scan_checks += (chk_a ? 1u : 0u) + (chk_b ? 1u : 0u);
+                    tally.scan_violations += ((chk_a && !((L.mask >> (L.node & 63u)) & 1ull)) ? 1u : 0u) + ((chk_b && !((L.mask >> ((L.node + 1u) & 63u)) & 1ull)) ? 1u : 0u);
+                }
+            }
             if (enter_a | enter_b) {
-                L.pend = enter_a ? (i | (kind_a << 30)) : ((i + 1u) | (kind_b << 30));
+                L.pend = enter_a ? (L.node | (kind_a << 30)) : ((L.node + 1) | (kind_b << 30));
                 return S_XFORM;
             }
-            L.node = first_candidate();
+            L.node = jump_a ? after_a : ((sh & obj_b) ? after_b : L.node + 2);
             return after_scan();
-        }
-        const bool obj_a = kind_a != CRT_OBJ_NONE, obj_b = kind_b != CRT_OBJ_NONE;
-        const bool enter_a = obj_a & hitA & (sh | (tA < L.hz));
-        const bool jump_a = sh & obj_a & (after_a != L.node + 1);            // shadow ray past a missed subtree
-        const bool look_b = !(enter_a | jump_a);
-        const bool enter_b = look_b & obj_b & hitB & (sh | (tB < L.hz));
-        if (kCount) {
-            tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b & obj_b) ? 1u : 0u);
-            // every box the full scan finds hit must be a candidate of the mask the plain kernels scan by
-            if (S.scan_mask) {
-                const bool chk_a = obj_a & hitA, chk_b = look_b & obj_b & hitB;
-                tally.scan_checks += (chk_a ? 1u : 0u) + (chk_b ? 1u : 0u);
-                tally.scan_violations += ((chk_a && !((L.mask >> (L.node & 63u)) & 1ull)) ? 1u : 0u) + ((chk_b && !((L.mask >> ((L.node + 1u) & 63u)) & 1ull)) ? 1u : 0u);
-            }
-        }
-        if (enter_a | enter_b) {
-            L.pend = enter_a ? (L.node | (kind_a << 30)) : ((L.node + 1) | (kind_b << 30));
-            return S_XFORM;
-        }
-        L.node = jump_a ? after_a : ((sh & obj_b) ? after_b : L.node + 2);
-        return after_scan();
-    };
+        };
 
-    // ---- LEAF: the next two triangles of the pending leaf, one after the other (IntersectTriangle /
-    // IntersectShadowTriangle, objects.cu:270-366); both records are fetched up front so that the
-    // pair costs one memory round trip
-    auto tri_test = [&](const float4 v0, const float4 v1, const float4 v2, uint32_t slot) -> bool {
-        TALLY(tri_tests);
-        // Same operations and order as the scalar form; independent products and sums of the two cross
-        // products and of the dot products are paired into packed instructions.
-        const f2 ex = f2{v1.x, v2.x} - v0.x, ey = f2{v1.y, v2.y} - v0.y, ez = f2{v1.z, v2.z} - v0.z;   // (edge1, edge2)
-        f2 odx = L.pdx, ody = L.pdy, odz = L.pdz;                                                        // (offset, dir)
-        odx.x -= v0.x; ody.x -= v0.y; odz.x -= v0.z;
-        // (oXe1, rXe2) = (cross(offset, edge1), cross(dir, edge2)), component-wise as in cross()
-        const f2 cx = ody * ez - ey * odz;
-        const f2 cy = -(odx * ez - ex * odz);
-        const f2 cz = odx * ey - ex * ody;
-        // (det, t numerator) = (dot(edge1, rXe2), dot(edge2, oXe1)); (b1, b2 numerators) = (dot(offset, rXe2), dot(dir, oXe1)):
-        // each pair multiplies by the cross products with their halves swapped
-        const f2 u = ex * cx.yx + ey * cy.yx + ez * cz.yx;
-        const f2 w = odx * cx.yx + ody * cy.yx + odz * cz.yx;
-        const f3 edge1 = mk3(ex.x, ey.x, ez.x), edge2 = mk3(ex.y, ey.y, ez.y), dir = mk3(odx.y, ody.y, odz.y);
-        const float det = u.x;
-        bool ok = !(det > -CRT_TRI_EPS && det < CRT_TRI_EPS);
-        const float idet = 1 / det;
-        const float b1 = idet * w.x;
-        ok = ok && !(b1 <= CRT_TRI_EPS || b1 >= 1 + CRT_TRI_EPS);
-        const float b2 = idet * w.y;
-        ok = ok && !(b2 <= -CRT_TRI_EPS || (b1 + b2) >= 1 + CRT_TRI_EPS);
-        const float t = idet * u.y;
-        const float far_limit = (L.shadow ? L.limit : L.hz) + CRT_TRI_EPS;
-        ok = ok && !(t <= CRT_TRI_EPS || t >= far_limit);
-        const float ndot = dot(cross(edge1, edge2), dir);
-        ok = ok && ((ndot < CRT_TRI_EPS) || (ndot > -CRT_TRI_EPS));
-        if (ok && !L.shadow) {
-            TALLY(tri_hits);
-            L.hz = t;
-            L.mesh_hit = true;
-            L.h_kind = H_MESH; L.h_node = L.entered; L.h_a = b1; L.h_b = b2; L.h_c = slot; L.h_front = ndot < 0;
-        }
-        return ok;
-    };
-    auto op_leaf = [&]() -> uint32_t {
-        const uint32_t slot = leaf_start(L.pend), count = leaf_count(L.pend);
-        const bool two = count >= 2;
-        const uint32_t second = two ? slot + 1 : slot;      // a single triangle is fetched twice rather than reading past the leaf
-        const uint32_t left = count - (two ? 2u : 1u);
-        L.pend = make_leaf_ref(slot + (two ? 2u : 1u), left);
-        const float4* tp = reinterpret_cast<const float4*>(tris + slot);
-        const float4* tq = reinterpret_cast<const float4*>(tris + second);
-        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-        const float4 b0 = tq[0], b1 = tq[1], b2 = tq[2];
-        if (tri_test(a0, a1, a2, slot) && L.shadow) return shadow_blocked();
-        if (two && tri_test(b0, b1, b2, second) && L.shadow) return shadow_blocked();
-        if (left) return S_LEAF;
-        return resolve(false, 0, 0);
-    };
-
-    // ---- XFORM: enter a scene node (Node::ToLocal, then the sphere / plane test in place or the
-    // start of a BVH walk: trace.cu:61-66, 188-191; objects.cu:7-159) or leave a mesh (world
-    // position of its hit, Node::FromLocal for the ray: trace.cu:64-66, 191)
-    auto op_xform = [&]() -> uint32_t {
-        const bool leaving = L.pend == kPendExit;
-        const uint32_t idx = leaving ? L.entered : (L.pend & 0x1fffffffu);
-        const uint32_t kind = L.pend >> 30;
-        // the whole 112-byte record is fetched at once (both matrices and the tags) so that no second
-        // memory round trip follows the object test
-        const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
-        const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r3 = xp[3], r4 = xp[4], r5 = xp[5], r6 = xp[6];
-        const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-        const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
-        if (leaving) {
-            if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
-            L.trav = false;
-        } else {
-            TALLY(node_enters);
-            xform_ray(itm, L.pdx, L.pdy, L.pdz);
-            if (kind == CRT_OBJ_MESH) {
-                L.qinv = recip3(L.qdir());
-                L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
-                return resolve(true, __float_as_uint(r6.x), 0.0f);
-            }
-            const f3 pos = L.qpos(), dir = L.qdir();
-            bool got = false, front = true;
-            float t = 0;
-            if (kind == CRT_OBJ_SPHERE) {
-                TALLY(sphere_tests);
-                if (!(dot(dir, pos) >= 0)) {
-                    const float a = dot(dir, dir);
-                    const float b = dot(dir, pos) * 2;
-                    const float c = dot(pos, pos) - 1;
-                    const float det = b * b - 4 * a * c;
-                    if (!(det < 0)) {
-                        const float sq = sqrtf(det);
-                        const float tf = (-b - sq) / (2 * a);
-                        const float tb = (-b + sq) / (2 * a);
-                        if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
-                        else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
-                        else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
-                    }
-                }
-            } else {
-                TALLY(plane_tests);
-                if (!(dir.z == 0)) {
-                    t = -pos.z / dir.z;
-                    const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
-                    if (in_range && ((dir.z < 0) || (dir.z > 0))) {
-                        const f3 p = pos + t * dir;
-                        if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
-                    }
-                }
-            }
-            if (got) {
-                if (L.shadow) return shadow_blocked();
-                const f3 p = pos + t * dir;
+        // ---- LEAF: the next two triangles of the pending leaf, one after the other (IntersectTriangle /
+        // IntersectShadowTriangle, objects.cu:270-366); both records are fetched up front so that the
+        // pair costs one memory round trip
+        auto tri_test = [&](const float4 v0, const float4 v1, const float4 v2, uint32_t slot) -> bool {
+            TALLY(tri_tests);
+            // Same operations and order as the scalar form; independent products and sums of the two cross
+            // products and of the dot products are paired into packed instructions.
+            const f2 ex = f2{v1.x, v2.x} - v0.x, ey = f2{v1.y, v2.y} - v0.y, ez = f2{v1.z, v2.z} - v0.z;   // (edge1, edge2)
+            f2 odx = L.pdx, ody = L.pdy, odz = L.pdz;                                                        // (offset, dir)
+            odx.x -= v0.x; ody.x -= v0.y; odz.x -= v0.z;
+            // (oXe1, rXe2) = (cross(offset, edge1), cross(dir, edge2)), component-wise as in cross()
+            const f2 cx = ody * ez - ey * odz;
+            const f2 cy = -(odx * ez - ex * odz);
+            const f2 cz = odx * ey - ex * ody;
+            // (det, t numerator) = (dot(edge1, rXe2), dot(edge2, oXe1)); (b1, b2 numerators) = (dot(offset, rXe2), dot(dir, oXe1)):
+            // each pair multiplies by the cross products with their halves swapped
+            const f2 u = ex * cx.yx + ey * cy.yx + ez * cz.yx;
+            const f2 w = odx * cx.yx + ody * cy.yx + odz * cz.yx;
+            const f3 edge1 = mk3(ex.x, ey.x, ez.x), edge2 = mk3(ex.y, ey.y, ez.y), dir = mk3(odx.y, ody.y, odz.y);
+            const float det = u.x;
+            bool ok = !(det > -CRT_TRI_EPS && det < CRT_TRI_EPS);
+            const float idet = 1 / det;
+            const float b1 = idet * w.x;
+            ok = ok && !(b1 <= CRT_TRI_EPS || b1 >= 1 + CRT_TRI_EPS);
+            const float b2 = idet * w.y;
+            ok = ok && !(b2 <= -CRT_TRI_EPS || (b1 + b2) >= 1 + CRT_TRI_EPS);
+            const float t = idet * u.y;
+            const float far_limit = (L.shadow ? L.limit : L.hz) + CRT_TRI_EPS;
+            ok = ok && !(t <= CRT_TRI_EPS || t >= far_limit);
+            const float ndot = dot(cross(edge1, edge2), dir);
+            ok = ok && ((ndot < CRT_TRI_EPS) || (ndot > -CRT_TRI_EPS));
+            if (ok && !L.shadow) {
+                TALLY(tri_hits);
                 L.hz = t;
-                L.hpos = xform_point(tm, p);
-                L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
-                L.h_node = idx; L.h_front = front;
-                L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
+                L.mesh_hit = true;
+                L.h_kind = H_MESH; L.h_node = L.entered; L.h_a = b1; L.h_b = b2; L.h_c = slot; L.h_front = ndot < 0;
             }
-        }
-        xform_ray(tm, L.pdx, L.pdy, L.pdz);
-        L.qinv = recip3(L.qdir());
-        L.node = by_mask ? first_candidate() : idx + 1;
-        return after_scan();
-    };
+            return ok;
+        };
+        auto op_leaf = [&]() -> uint32_t {
+            const uint32_t slot = leaf_start(L.pend), count = leaf_count(L.pend);
+            const bool two = count >= 2;
+            const uint32_t second = two ? slot + 1 : slot;      // a single triangle is fetched twice rather than reading past the leaf
+            const uint32_t left = count - (two ? 2u : 1u);
+            L.pend = make_leaf_ref(slot + (two ? 2u : 1u), left);
+            const float4* tp = reinterpret_cast<const float4*>(tris + slot);
+            const float4* tq = reinterpret_cast<const float4*>(tris + second);
+            const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+            const float4 b0 = tq[0], b1 = tq[1], b2 = tq[2];
+            if (tri_test(a0, a1, a2, slot) && L.shadow) return shadow_blocked();
+            if (two && tri_test(b0, b1, b2, second) && L.shadow) return shadow_blocked();
+            if (left) return S_LEAF;
+            return resolve(false, 0, 0);
+        };
 
-    // ---- PATH: everything between two ray queries of a pixel (TracePath, trace.cu:83-158)
-    auto op_path = [&]() -> uint32_t {
-        bool want_shadow = false, alive = false;
-        f3 spos = mk3(0, 0, 0), sdir = mk3(0, 0, 1);
-        float sdist = 0;
-        // the pixel's three accumulators are updated in place (renderer/trace.cu:39, 92-141)
-        float* __restrict__ acc_target = S.results + 3ull * L.pI;
-        float* __restrict__ acc_normal = S.normals + 3ull * L.pI;
-        float* __restrict__ acc_albedo = S.albedos + 3ull * L.pI;
-        // Section clock of the counted build: one stamp per wave in LDS, advanced by the first active
-        // lane, so that a section's cycles are counted once per turn whichever lanes run it.
-        if (kCount && lane_rank(__ballot(true)) == 0) sect_clock[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
-#define SECT(i) do { if (kCount && lane_rank(__ballot(true)) == 0) { \
-            const unsigned long long t_n = __builtin_amdgcn_s_memtime(); \
-            path_sections[(threadIdx.x >> 6) * 8 + i] += t_n - sect_clock[threadIdx.x >> 6]; sect_clock[threadIdx.x >> 6] = t_n; } } while (0)
-        Rng rng;
-        rng.d = cold_ld(C_RNG); rng.v0 = cold_ld(C_RNG + 1); rng.v1 = cold_ld(C_RNG + 2);
-        rng.v2 = cold_ld(C_RNG + 3); rng.v3 = cold_ld(C_RNG + 4); rng.v4 = cold_ld(C_RNG + 5);
-        f3 contrib = cold_ld3(C_CONTRIB);
-        int sample = (int)cold_ld(C_SAMPLE);
-        uint32_t segments = cold_ld(C_SEGMENTS);
-        uint32_t cost = cold_ld(C_COST);
-        f3 next_dir = mk3(0, 0, 1);
+        // ---- XFORM: enter a scene node (Node::ToLocal, then the sphere / plane test in place or the
+        // start of a BVH walk: trace.cu:61-66, 188-191; objects.cu:7-159) or leave a mesh (world
+        // position of its hit, Node::FromLocal for the ray: trace.cu:64-66, 191)
+        auto op_xform = [&]() -> uint32_t {
+            const bool leaving = L.pend == kPendExit;
+            const uint32_t idx = leaving ? L.entered : (L.pend & 0x1fffffffu);
+            const uint32_t kind = L.pend >> 30;
+            // the whole 112-byte record is fetched at once (both matrices and the tags) so that no second
+            // memory round trip follows the object test
+            const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
+            const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r3 = xp[3], r4 = xp[4], r5 = xp[5], r6 = xp[6];
+            const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
+            if (leaving) {
+                if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
+                L.trav = false;
+            } else {
+                TALLY(node_enters);
+                xform_ray(itm, L.pdx, L.pdy, L.pdz);
+                if (kind == CRT_OBJ_MESH) {
+                    L.qinv = recip3(L.qdir());
+                    L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
+                    return resolve(true, __float_as_uint(r6.x), 0.0f);
+                }
+                const f3 pos = L.qpos(), dir = L.qdir();
+                bool got = false, front = true;
+                float t = 0;
+                if (kind == CRT_OBJ_SPHERE) {
+                    TALLY(sphere_tests);
+                    if (!(dot(dir, pos) >= 0)) {
+                        const float a = dot(dir, dir);
+                        const float b = dot(dir, pos) * 2;
+                        const float c = dot(pos, pos) - 1;
+                        const float det = b * b - 4 * a * c;
+                        if (!(det < 0)) {
+                            const float sq = sqrtf(det);
+                            const float tf = (-b - sq) / (2 * a);
+                            const float tb = (-b + sq) / (2 * a);
+                            if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
+                            else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
+                            else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
+                        }
+                    }
+                } else {
+                    TALLY(plane_tests);
+                    if (!(dir.z == 0)) {
+                        t = -pos.z / dir.z;
+                        const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
+                        if (in_range && ((dir.z < 0) || (dir.z > 0))) {
+                            const f3 p = pos + t * dir;
+                            if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
+                        }
+                    }
+                }
+                if (got) {
+                    if (L.shadow) return shadow_blocked();
+                    const f3 p = pos + t * dir;
+                    L.hz = t;
+                    L.hpos = xform_point(tm, p);
+                    L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
+                    L.h_node = idx; L.h_front = front;
+                    L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
+                }
+            }
+            xform_ray(tm, L.pdx, L.pdy, L.pdz);
+            L.qinv = recip3(L.qdir());
+            L.node = by_mask ? first_candidate() : idx + 1;
+            return after_scan();
+        };
 
-        if (L.pk == PK_SHADOW_CLEAR || L.pk == PK_SHADOW_BLOCKED) {
-            // end of TraceShadowRay: add the light sample if nothing was in the way (trace.cu:137-143)
-            const uint32_t flags = cold_ld(C_FLAGS);
-            if (L.pk == PK_SHADOW_CLEAR && (flags & 1u)) acc_add(acc_target, cold_ld3(C_NEE));
-            alive = (flags & 2u) != 0;
-            next_dir = cold_ld3(C_NDIR);
-        } else if (L.pk == PK_CLOSEST_DONE) {
-            // lights are intersected last, with the ray as the node loop left it (trace.cu:72-78)
-            int hit_light = -1;
-            f3 light_n = mk3(0, 0, 0);
-            for (uint32_t i = 0; i < S.light_count; i++) {
-                const DevLight Li = S.lights[i];
-                if (Li.kind != CRT_LIGHT_POINT) continue;
-                // PointLight::Intersect (scene/lights.cu:36-89)
-                const f3 lp = ld3(Li.pos);
-                const f3 o = L.qpos() - lp;
-                const float a = dot(L.qdir(), L.qdir());
-                const float b = dot(2 * L.qdir(), o);
-                const float c = dot(o, o) - Li.size * Li.size;
-                const float det = b * b - 4 * a * c;
-                if (det < 0) continue;
-                const float sq = sqrtf(det);
-                const float tf = (-b - sq) / (2 * a);
-                const float tb = (-b + sq) / (2 * a);
-                if (tf >= 0) {
-                    if (tf >= L.hz) continue;
-                    L.hz = tf;
-                    light_n = normalized(o);
-                    L.hpos = L.qpos() + tf * L.qdir();
-                    hit_light = (int)i;
+        // ---- EXCHANGE: lanes whose query has ended write its result into their slot and queue the slot for
+        // shading; they and the lanes that were idle already then take the next ready queries, whichever pixels
+        // those belong to
+        auto op_exchange = [&]() {
+            const bool post = state == S_POST;
+            if (post) {
+                uint32_t* rec = slot_rec(L.slot) + kRecHit;
+                if (L.pk == PK_CLOSEST_DONE) {
+                    uint4* r4 = reinterpret_cast<uint4*>(rec);
+                    const f3 qp = L.qpos(), qd = L.qdir();
+                    r4[0] = uint4{L.pk, __float_as_uint(L.hz), L.h_kind | (L.h_front ? 4u : 0u) | (L.h_node << 3), L.h_c};
+                    r4[1] = uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), __float_as_uint(L.h_a)};
+                    r4[2] = uint4{__float_as_uint(qp.x), __float_as_uint(qp.y), __float_as_uint(qp.z), __float_as_uint(L.h_b)};
+                    r4[3] = uint4{__float_as_uint(qd.x), __float_as_uint(qd.y), __float_as_uint(qd.z), 0u};
+                } else {
+                    rec[0] = L.pk;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            queue_push(&ctl.shade_tail, shade_ring, post, L.slot);
+            if (post) state = S_IDLE;
+            uint32_t slot = 0;
+            const bool got = queue_pop(&ctl.ray_head, &ctl.ray_tail, ray_ring, state == S_IDLE, 1u, n_slots, slot, &ctl.abort);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (kCount) { const uint32_t n_got = (uint32_t)__popcll(__ballot(got)); if ((tid & 63u) == 0) tally.cycles[5] += n_got; }
+            if (got) {
+                const uint4* r4 = reinterpret_cast<const uint4*>(slot_rec(slot) + kRecRay);
+                const uint4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
+                L.slot = slot;
+                L.pdx = f2{__uint_as_float(a.x), __uint_as_float(b.x)};
+                L.pdy = f2{__uint_as_float(a.y), __uint_as_float(b.y)};
+                L.pdz = f2{__uint_as_float(a.z), __uint_as_float(b.z)};
+                L.limit = __uint_as_float(a.w);
+                L.shadow = (b.w & 1u) != 0;
+                L.qinv = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+                L.node = c.w;
+                L.mask = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
+                L.trav = false;
+                L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
+                // no node of the scene can be hit at all: the query is over before its first box step
+                state = after_scan();
+            }
+        };
+
+        // ---- the scheduler of a traversal wave ------------------------------------------------------
+        for (;;) {
+            // Which operation runs this turn.  Box steps are the bulk of the work and run whenever
+            // sched_box_min lanes want one.  Otherwise a cheap traversal operation (triangle, transform)
+            // runs once sched_special_min lanes wait for it, an exchange once sched_exchange_min lanes have a
+            // result to post or nothing to do; failing that whatever has lanes.
+            uint32_t n_box = (uint32_t)__popcll(__ballot(state == S_BOX));
+            // box burst: this inner loop carries only the few values a box step changes.  It ends as soon as enough
+            // lanes have a result to post: an exchange is cheap and gives them their next query.
+            while (n_box >= S.sched_box_min && (uint32_t)__popcll(__ballot(state == S_POST)) < S.sched_exchange_min) {
+                unsigned long long t_box = 0;
+                if (kCount) { t_box = __builtin_amdgcn_s_memtime(); tally.turns[0]++; tally.lanes[0] += state == S_BOX; }
+                if (state == S_BOX) state = op_box();
+                if (kCount) tally.cycles[0] += __builtin_amdgcn_s_memtime() - t_box;
+                n_box = (uint32_t)__popcll(__ballot(state == S_BOX));
+            }
+            uint32_t best;
+            {
+                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(state == S_LEAF));
+                const uint32_t n_xf = (uint32_t)__popcll(__ballot(state == S_XFORM));
+                const uint32_t n_post = (uint32_t)__popcll(__ballot(state == S_POST));
+                const uint32_t n_idle = 64u - n_box - n_leaf - n_xf - n_post;
+                const uint32_t special = n_leaf >= n_xf ? (uint32_t)S_LEAF : (uint32_t)S_XFORM;
+                const uint32_t n_special = n_leaf >= n_xf ? n_leaf : n_xf;
+                // idle lanes count toward an exchange only while the ray queue has something for them
+                uint32_t n_take = 0;
+                if (n_idle) { const uint32_t avail = lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head); n_take = avail < n_idle ? avail : n_idle; }
+                const uint32_t n_ex = n_post + n_take;
+                if (kCount) {      // census at every vote: lanes without a query, and (once per wave) the fill of the two queues
+                    tally.turns[6]++; tally.lanes[6] += state == S_IDLE; tally.lanes[7] += state == S_POST;
+                    if ((tid & 63u) == 0) { tally.cycles[6] += lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head); tally.cycles[7] += lds_ld(&ctl.shade_tail) - lds_ld(&ctl.shade_head); }
+                }
+                if (n_ex >= S.sched_exchange_min) best = S_POST;
+                else if (n_special >= S.sched_special_min) best = special;
+                else if (n_box > 0) best = S_BOX;
+                else if (n_special > 0) best = special;
+                else if (n_ex > 0) best = S_POST;
+                else {
+                    // every lane idle and no query ready
+                    if (!idle_wait()) break;
                     continue;
                 }
-                if (tb < 0) continue;
-                if (tb >= L.hz) continue;
-                L.hz = tb;
-                light_n = normalized(L.hpos);      // the previous hit position, as the reference reads it (lights.cu:78)
-                L.hpos = L.qpos() + tb * L.qdir();
-                hit_light = (int)i;
             }
-            const bool any = hit_light >= 0 || L.h_kind != H_NONE;
-            SECT(0);
-
-            if (kPrimary) {
-                int32_t id = -1, face = -1;
-                if (hit_light >= 0) id = -2 - hit_light;
-                else if (any) { id = (int32_t)L.h_node; if (L.h_kind == H_MESH) face = (int32_t)tris[L.h_c].face; }
-                out_node[L.pI] = id; out_face[L.pI] = face; out_t[L.pI] = L.hz;
-            } else if (!any) {
-                const f3 env = tex_env<kCount>(S, L.qdir(), tally);
-                acc_add(acc_target, contrib * env);
-                acc_add(acc_normal, contrib * normalized(L.qdir()));
-                acc_add(acc_albedo, contrib * env);
-            } else if (hit_light >= 0) {
-                const f3 rad = ld3(S.lights[hit_light].radiance);
-                acc_add(acc_target, contrib * rad);
-                acc_add(acc_normal, contrib * light_n);
-                acc_add(acc_albedo, contrib * rad);
-            } else {
-                // normal and texture coordinates of the hit (objects.cu:44-50, 126-131, 308-320) and
-                // Node::FromLocal for the normal (scene/scene.cuh:185-189)
-                const NodeXf* __restrict__ xf = S.xf + L.h_node;
-                f3 n, uvw;
-                if (L.h_kind == H_MESH) {
-                    // interpolated vertex normal and texture vertex of the hit triangle (objects.cu:308-320)
-                    const float b1 = L.h_a, b2 = L.h_b;
-                    const float b0 = 1 - b2 - b1;
-                    const float4* ap = reinterpret_cast<const float4*>(S.attrs + L.h_c);
-                    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
-                    const uint32_t mesh_flags = xf->flags;
-                    if (!(mesh_flags & kXfHasNormals)) {
-                        const float4* tp = reinterpret_cast<const float4*>(tris + L.h_c);
-                        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                        const f3 p0 = mk3(v0.x, v0.y, v0.z);
-                        n = normalized(cross(mk3(v1.x, v1.y, v1.z) - p0, mk3(v2.x, v2.y, v2.z) - p0));
-                    } else {
-                        n = mk3(a0.x, a0.y, a0.z) * b0 + mk3(a0.w, a1.x, a1.y) * b1 + mk3(a1.z, a1.w, a2.x) * b2;
-                    }
-                    if (!(mesh_flags & kXfHasTex)) uvw = mk3(0, 0, 0);
-                    else uvw = mk3(a2.y, a2.z, a2.w) * b0 + mk3(a3.x, a3.y, a3.z) * b1 + mk3(a3.w, a4.x, a4.y) * b2;
-                } else {
-                    const f3 p = mk3(L.h_a, L.h_b, __uint_as_float(L.h_c));
-                    if (L.h_kind == H_SPHERE) {
-                        n = p;
-                        uvw = mk3(0.5f * 0.318309f * crtm::det_atan2f(p.y, p.x) + 0.5f,
-                                  0.318309f * crtm::det_asinf(fminf(fmaxf(p.z, -1.0f), 1.0f)) + 0.5f, 0);
-                    } else {
-                        n = mk3(0, 0, 1);
-                        uvw = 0.5f * (p + mk3(1, 1, 0));
-                    }
+            idle_polls = 0;
+            unsigned long long t_start = 0;
+            if (kCount) t_start = __builtin_amdgcn_s_memtime();
+            switch (best) {
+                case S_BOX: {
+                    // below the burst threshold: keep stepping while every lane that took the step wants another one
+                    // (the lone lanes at the end of a frame are the common case), then vote again
+                    uint32_t n_now;
+                    do {
+                        if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; }
+                        if (state == S_BOX) state = op_box();
+                        n_now = (uint32_t)__popcll(__ballot(state == S_BOX));
+                    } while (n_now == n_box);
+                    break;
                 }
-                n = xform_normal(xf->itm, n);
-                SECT(1);
-                const f3 hpos = L.hpos;
-                const f3 v = cold_ld3(C_V);
-
-                const float light_pick = rng_float(rng);
-                const DevMaterial mtl = S.materials[xf->material_id];
-                const f3 kD = tex_eval<kCount>(S, mtl.diffuse, uvw, tally);
-                const f3 kS = tex_eval<kCount>(S, mtl.specular, uvw, tally);
-                const f3 kT = tex_eval<kCount>(S, mtl.refraction, uvw, tally);
-                const f3 kE = tex_eval<kCount>(S, mtl.emission, uvw, tally);
-                SECT(2);
-                acc_add(acc_normal, contrib * n);
-                acc_add(acc_albedo, contrib * kD + kE);
-                acc_add(acc_target, contrib * kE);
-
-                // lobe probabilities (renderer/shading.cu:17-29 and 122-134)
-                const float third = 1.0f / 3.0f;
-                float pD = (kD.x + kD.y + kD.z) * third;
-                float pS = (kS.x + kS.y + kS.z) * third;
-                float pT = (kT.x + kT.y + kT.z) * third;
-                if (pD + pS + pT > CRT_MAX_SURVIVAL) {
-                    const float norm = CRT_MAX_SURVIVAL / (pD + pS + pT);
-                    pD *= norm; pS *= norm; pT *= norm;
-                }
-                const float g = mtl.glossiness;
-
-                // next-event estimation toward one light (trace.cu:112-143).  Ambient and directional
-                // lights produce no sample and zero weight, so nothing is traced for them; with no
-                // light at all (where the reference reads a null light) no sample is taken either.
-                bool nee_valid = false;
-                if (S.light_count > 0) {
-                    const int light_id = crtm::f2i_sat(light_pick * (float)S.light_count);
-                    const DevLight Ls = S.lights[light_id];
-                    if (Ls.kind == CRT_LIGHT_POINT) {
-                        // PointLight::GenerateSample (scene/lights.cu:10-34)
-                        const f3 lp = ld3(Ls.pos);
-                        const f3 Ldir = normalized(hpos - lp);
-                        const float x = rng_float(rng);
-                        const float phi = rng_float(rng) * 2 * F_PI;
-                        const float cos_theta = 1 - x;
-                        const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-                        f3 a, b;
-                        orthonormals(Ldir, a, b);
-                        float sin_phi, cos_phi;
-                        crtm::det_sincosf(phi, sin_phi, cos_phi);
-                        const f3 ln = Ldir * cos_theta + a * sin_theta * cos_phi + b * sin_theta * sin_phi;
-                        const f3 tgt = lp + ln * Ls.size;
-                        const f3 ldir = normalized(tgt - hpos);
-                        const float d2 = lengthsq(tgt - hpos);
-                        const float cos_theta_l = dot(ldir, -normalized(tgt - lp));
-                        const float l_prob = d2 / (2 * F_PI * Ls.size * Ls.size * cos_theta_l);
-                        const f3 l_mult = ld3(Ls.radiance);
-                        sdist = sqrtf(d2);
-                        // Material::GetSampleInfo (renderer/shading.cu:116-150)
-                        float b_prob = 0.0f;
-                        f3 b_mult = mk3(0, 0, 0);
-                        const float ndl = dot(n, ldir);
-                        if (ndl >= 0) {
-                            b_prob += pD * (ndl > 0 ? OVERPI : 0);
-                            b_mult += kD * OVERPI * ndl;
-                            const f3 rn = normalized(v + ldir);
-                            const float ndh = dot(n, rn);
-                            b_prob += pS * (g + 1) * 0.5f * OVERPI * crtm::det_powf(ndh, g + 1);
-                            b_mult += kS * (g + 2) * 0.125f * OVERPI * crtm::det_powf(ndh, g);
-                        }
-                        const float denom = l_prob * l_prob + b_prob * b_prob;
-                        if (denom > CRT_F_EPS && l_prob > CRT_F_EPS) {
-                            const float pop = l_prob / denom;
-                            cold_st3(C_NEE, contrib * l_mult * b_mult * pop);
-                            nee_valid = true;
-                        }
-                        // TraceShadowRay prologue (trace.cu:160-162)
-                        spos = hpos; sdir = ldir;
-                        spos += sdir * CRT_BIAS + n * CRT_BIAS;
-                        want_shadow = true;
-                    }
-                }
-
-                SECT(3);
-                // Material::GenerateSample (renderer/shading.cu:11-113)
-                f3 kA = mk3(1, 1, 1);
-                if (!L.h_front) {
-                    const f3 e = ld3(mtl.absorption) * -L.hz;
-                    kA = mk3(crtm::det_expf(e.x), crtm::det_expf(e.y), crtm::det_expf(e.z));
-                }
-                const float p = rng_float(rng);
-                f3 ndir = mk3(0, 0, 0), n_mult = mk3(0, 0, 0);
-                float n_prob = 0;
-                bool sampled = true;
-                if (p < pD) {
-                    const float x = rng_float(rng);
-                    const float phi = rng_float(rng) * 2 * F_PI;
-                    const float cos_theta = 1 - x;
-                    const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-                    f3 u, w;
-                    orthonormals(n, u, w);
-                    float sin_phi, cos_phi;
-                    crtm::det_sincosf(phi, sin_phi, cos_phi);
-                    ndir = n * cos_theta + u * sin_theta * cos_phi + w * sin_theta * sin_phi;
-                    n_prob = pD * OVERPI;
-                    n_mult = kA * kD * OVERPI * dot(n, ndir);
-                } else {
-                    const f3 gln = glossy_normal(n, g, rng);
-                    if (p < pD + pS) {
-                        ndir = reflect(v, gln);
-                        const float pw = crtm::det_powf(dot(gln, n), g);
-                        n_prob = pS * (g + 1) * 0.125f * OVERPI * pw;
-                        n_mult = kA * kS * (g + 2) * 0.125f * OVERPI * pw;
-                    } else if (p < pD + pS + pT) {
-                        const float eta_i = L.h_front ? 1 : mtl.ior;
-                        const float eta_o = L.h_front ? mtl.ior : 1;
-                        const f3 h = L.h_front ? gln : -gln;
-                        bool tir = false;
-                        ndir = transmit(v, h, eta_i, eta_o, tir);
-                        const float f_0 = crtm::det_powf((eta_i - eta_o) / (eta_i + eta_o), 2);
-                        const float cos_theta = dot(v, h);
-                        float f_theta = f_0 + (1 - f_0) * crtm::det_powf(1 - cos_theta, 5);
-                        f_theta = fminf(fmaxf(f_theta, 0.0f), 1.0f);
-                        if (!tir) {
-                            if (rng_float(rng) >= f_theta) {
-                                n_prob = pT * (1 - f_theta);
-                                n_mult = kA * kT * (1 - f_theta);
-                            } else {
-                                ndir = reflect(v, h);
-                                n_prob = pT * f_theta;
-                                n_mult = kA * kT * f_theta;
-                            }
-                        } else {
-                            n_prob = pT;
-                            n_mult = kA * kT;
-                        }
-                    } else {
-                        sampled = false;
-                    }
-                }
-                // the path continues unless the sample died, its probability vanished or the safety bound hit
-                if (sampled) {
-                    next_dir = ndir;
-                    if (!(n_prob <= CRT_F_EPS)) {
-                        contrib *= n_mult * (1.0f / n_prob);
-                        alive = ++segments < CRT_MAX_SEGMENTS;
-                    }
-                }
-                if (want_shadow) {
-                    cold_st3(C_NDIR, next_dir);
-                    cold_st(C_FLAGS, (nee_valid ? 1u : 0u) | (alive ? 2u : 0u));
-                }
+                case S_LEAF: if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); break;
+                case S_XFORM: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_XFORM; } if (state == S_XFORM) state = op_xform(); break;
+                default:
+                    if (kCount) { tally.turns[4]++; tally.lanes[4] += (state == S_POST || state == S_IDLE); }
+                    op_exchange();
+                    break;
+            }
+            if (kCount) {
+                const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+                switch (best) { case S_BOX: tally.cycles[0] += dt; break; case S_LEAF: tally.cycles[1] += dt; break; case S_XFORM: tally.cycles[2] += dt; break; default: tally.cycles[4] += dt; break; }
             }
         }
+    } else {
+        // =====================================================================================================
+        // shading waves: everything between two ray queries of a pixel (TracePath, trace.cu:83-158), the camera
+        // ray of a new path (trace.cu:14-38) and the next pixel of a finished slot
+        // =====================================================================================================
+        const float F_PI = 3.14159265358979323846f;
+        const float OVERPI = (float)(1.0f / 3.14159265358979323846);
+        const float inv_samples = 1.0f / (float)samples;
+        bool queue_empty = false;
+        // The traversal lanes of the whole block wait on what these few waves produce: they go first whenever they
+        // have work (they sleep when they have none).
+        if (S.serve_priority) __builtin_amdgcn_s_setprio(3);
 
-        SECT(4);
-        // ---- what comes next for this pixel
-        uint32_t next_state = S_BOX;
-        if (want_shadow) {
-            tally.shadow_rays++;
-            L.set_qpos(spos); L.set_qdir(sdir); L.qinv = recip3(sdir);
-            L.limit = sdist;
-            L.shadow = true; L.trav = false; L.node = 0;
-        } else {
-            bool have_ray = true;
-            if (alive) {
-                L.set_qpos(L.hpos);
-                L.set_qdir(next_dir);
-            } else if (L.pk != PK_NEW_PATH && ++sample >= samples) {
-                have_ray = false;
-                next_state = S_FETCH;
-                if (!kPrimary && P.tile_cost) atomicMax(P.tile_cost + cold_ld(C_TILE), cost);
-            } else {
-                // a new path: camera ray (trace.cu:26-38)
-                const uint32_t pY = L.pI / S.width, pX = L.pI - pY * S.width;
-                f3 cam_pos, cam_dir;
-                camera_ray(S, pX, pY, rng, cam_pos, cam_dir);
-                L.set_qpos(cam_pos); L.set_qdir(cam_dir);
-                contrib = mk3(1, 1, 1) * inv_samples;
-                segments = 0;
-                TALLY(paths);
-            }
-            if (have_ray) {
-                // TraceThroughScene prologue (renderer/trace.cu:44-50)
-                cold_st3(C_V, -normalized(L.qdir()));
-                L.set_qpos(L.qpos() + L.qdir() * CRT_BIAS);
-                L.qinv = recip3(L.qdir());
-                L.limit = CRT_BIGFLOAT;
-                L.shadow = false; L.trav = false; L.node = 0;
-                L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
-                tally.closest_rays++;
-            }
-        }
-        cold_st(C_RNG, rng.d); cold_st(C_RNG + 1, rng.v0); cold_st(C_RNG + 2, rng.v1);
-        cold_st(C_RNG + 3, rng.v2); cold_st(C_RNG + 4, rng.v3); cold_st(C_RNG + 5, rng.v4);
-        cold_st3(C_CONTRIB, contrib);
-        cold_st(C_SAMPLE, (uint32_t)sample);
-        cold_st(C_SEGMENTS, segments);
-        cold_st(C_COST, cost + 1);
-        // one pass over the node boxes for whichever query the lane is about to start
-        if (S.scan_mask && next_state == S_BOX) {
-            L.mask = scan_candidates(S, pairs, L.qpos(), L.qdir(), L.limit, L.shadow);
-            if (by_mask) L.node = first_candidate();
-        }
-        // no node of the scene can be hit at all: the query is over before its first box step
-        if (by_mask && next_state == S_BOX && L.node >= node_count) next_state = query_done();
-        SECT(5);
-        return next_state;
-    };
+        // Section clock of the counted build: one stamp per wave in LDS, advanced by the first active
+        // lane, so that a section's cycles are counted once per turn whichever lanes run it.
+#define SECT(i) do { if (kCount && lane_rank(__ballot(true)) == 0) { \
+            const unsigned long long t_n = __builtin_amdgcn_s_memtime(); \
+            path_sections[wave * 8 + i] += t_n - sect_clock[wave]; sect_clock[wave] = t_n; } } while (0)
 
-    // ---- the scheduler ---------------------------------------------------------------------
-    for (;;) {
-        // Which operation runs this turn.  Box steps are the bulk of the work and run whenever
-        // sched_box_min lanes want one.  Otherwise a cheap traversal operation (triangle, transform)
-        // runs once sched_special_min lanes wait for it; failing that the fuller of box and path (lanes
-        // that wait for a pixel count as path lanes: a path turn serves them first); leftovers last.
-        uint32_t n_box = (uint32_t)__popcll(__ballot(state == S_BOX));
-        // box burst: this inner loop carries only the few values a box step changes
-        while (n_box >= S.sched_box_min) {
-            unsigned long long t_box = 0;
-            if (kCount) { t_box = __builtin_amdgcn_s_memtime(); tally.turns[0]++; tally.lanes[0] += state == S_BOX; }
-            if (state == S_BOX) state = op_box();
-            if (kCount) tally.cycles[0] += __builtin_amdgcn_s_memtime() - t_box;
-            n_box = (uint32_t)__popcll(__ballot(state == S_BOX));
-        }
-        uint32_t best = S_BOX;
-        {
-            const uint32_t n_leaf = (uint32_t)__popcll(__ballot(state == S_LEAF));
-            const uint32_t n_xf = (uint32_t)__popcll(__ballot(state == S_XFORM));
-            const uint32_t n_path = (uint32_t)__popcll(__ballot(state == S_PATH));
-            const uint32_t n_fetch = (uint32_t)__popcll(__ballot(state == S_FETCH));
-            const uint32_t special = n_leaf >= n_xf ? (uint32_t)S_LEAF : (uint32_t)S_XFORM;
-            const uint32_t n_special = n_leaf >= n_xf ? n_leaf : n_xf;
-            // a path turn starts by handing pixels to the lanes that wait for one, so both kinds count
-            const uint32_t heavy = S_PATH;
-            const uint32_t n_heavy = n_path + n_fetch;
-            if (n_special >= S.sched_special_min) best = special;
-            else if (n_box > 0 && n_box >= n_heavy) best = S_BOX;
-            else if (n_heavy >= S.sched_heavy_min || (n_heavy > 0 && n_box == 0 && n_special == 0)) best = heavy;
-            else if (n_special > 0) best = special;
-            else if (n_box > 0) best = S_BOX;
-            else if (n_heavy > 0) best = heavy;
-            else break;
-        }
-        unsigned long long t_start = 0;
-        if (kCount) t_start = __builtin_amdgcn_s_memtime();
-        switch (best) {
-            case S_BOX: {
-                // below the burst threshold: keep stepping while every lane that took the step wants another one
-                // (the lone lanes at the end of a frame are the common case), then vote again
-                uint32_t n_now;
-                do {
-                    if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; }
-                    if (state == S_BOX) state = op_box();
-                    n_now = (uint32_t)__popcll(__ballot(state == S_BOX));
-                } while (n_now == n_box);
-                break;
-            }
-            case S_LEAF: if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); break;
-            case S_XFORM: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_XFORM; } if (state == S_XFORM) state = op_xform(); break;
-            default: {
-                // FETCH: idle lanes take consecutive items from the pixel queue with one atomic per wave
-                const bool need = state == S_FETCH;
+        // one shading turn for the lane's slot; returns what becomes of the slot
+        auto serve = [&](bool have, uint32_t slot) -> uint32_t {
+            uint32_t result = R_NONE;
+            uint32_t* const rec = slot_rec(have ? slot : 0u);
+            uint32_t pk = have ? rec[kRecHit] : (uint32_t)PK_NEW_PATH;
+            Rng rng = {};
+            uint32_t pI = 0, tile = 0, cost = 0, segments = 0;
+            int sample = 0;
+            bool fresh = false;                                 // pixel taken this turn: nothing to load
+            f3 contrib = mk3(0, 0, 0), v = mk3(0, 0, 0);
+
+            // ---- a slot without a pixel takes the next one of the global queue: consecutive items, one atomic per wave
+            {
+                const bool need = have && pk == PK_FETCH;
                 const unsigned long long mask = __ballot(need);
                 if (mask != 0) {
-                    if (kCount) { tally.turns[4]++; tally.lanes[4] += need; }
-                    if (queue_empty) { if (need) state = S_DONE; }
+                    if (kCount) { tally.turns[5]++; tally.lanes[5] += need; }
+                    if (queue_empty) { if (need) result = R_RETIRE; }
                     else {
                         uint32_t base = 0;
                         const uint32_t cnt = (uint32_t)__popcll(mask);
                         if (need && lane_rank(mask) == 0) base = atomicAdd(queue, cnt);
                         base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-                        if (base + cnt >= P.total_items) { queue_empty = true; if (kCount && lane_rank(__ballot(true)) == 0 && wave_clock[(threadIdx.x >> 6) * 2 + 1] == 0) wave_clock[(threadIdx.x >> 6) * 2 + 1] = __builtin_amdgcn_s_memtime(); }      // uniform: the queue has run dry
+                        if (base + cnt >= P.total_items) {      // uniform: the queue has run dry
+                            queue_empty = true;
+                            if (kCount && lane_rank(__ballot(true)) == 0 && wave_clock[wave * 2 + 1] == 0) wave_clock[wave * 2 + 1] = __builtin_amdgcn_s_memtime();
+                        }
                         if (need) {
                             const uint32_t item = base + lane_rank(mask);
-                            uint32_t pX, pY, tile;
-                            if (item >= P.total_items) state = S_DONE;
+                            uint32_t pX, pY;
+                            if (item >= P.total_items) result = R_RETIRE;
                             else if (item_to_pixel(S, P, item, pX, pY, tile)) {
-                                L.pI = pY * S.width + pX;
-                                cold_st(C_TILE, tile); cold_st(C_COST, 0u);
-                                Rng rng;
-                                rng_init(rng, L.pI, jump);
-                                cold_st(C_RNG, rng.d); cold_st(C_RNG + 1, rng.v0); cold_st(C_RNG + 2, rng.v1);
-                                cold_st(C_RNG + 3, rng.v2); cold_st(C_RNG + 4, rng.v3); cold_st(C_RNG + 5, rng.v4);
-                                cold_st(C_SAMPLE, 0u);
-                                L.pk = PK_NEW_PATH;
-                                state = S_PATH;
-                            }                                   // else: item outside the image, fetch again
+                                pI = pY * S.width + pX;
+                                rng_init(rng, pI, jump);
+                                pk = PK_NEW_PATH;
+                                fresh = true;
+                            } else result = R_REFETCH;           // item outside the image: ask again
                         }
                     }
                 }
-                // PATH for every lane between two queries, the freshly fetched ones included
-                if (kCount) { tally.turns[3]++; tally.lanes[3] += state == S_PATH; tally.lanes[5] += state == S_DONE; tally.lanes[6] += state == S_FETCH; tally.lanes[7] += state == S_BOX; }
-                if (state == S_PATH) state = op_path();
-                break;
             }
+            if (!have || result != R_NONE) return result;
+
+            uint4* const path4 = reinterpret_cast<uint4*>(rec + kRecPath);
+            if (!fresh) {
+                const uint4 p0 = path4[0], p1 = path4[1], p2 = path4[2], p3 = path4[3];
+                rng.d = p0.x; rng.v0 = p0.y; rng.v1 = p0.z; rng.v2 = p0.w; rng.v3 = p1.x; rng.v4 = p1.y;
+                contrib = mk3(__uint_as_float(p1.z), __uint_as_float(p1.w), __uint_as_float(p2.x));
+                v = mk3(__uint_as_float(p2.y), __uint_as_float(p2.z), __uint_as_float(p2.w));
+                sample = (int)p3.x; segments = p3.y; cost = p3.z; pI = p3.w;
+            }
+
+            bool want_shadow = false, alive = false;
+            f3 spos = mk3(0, 0, 0), sdir = mk3(0, 0, 1);
+            float sdist = 0;
+            // the pixel's three accumulators are updated in place (renderer/trace.cu:39, 92-141)
+            float* __restrict__ acc_target = S.results + 3ull * pI;
+            float* __restrict__ acc_normal = S.normals + 3ull * pI;
+            float* __restrict__ acc_albedo = S.albedos + 3ull * pI;
+            f3 next_dir = mk3(0, 0, 1);
+            // the query's ray as the node loop left it, and its hit
+            f3 qpos = mk3(0, 0, 0), qdir = mk3(0, 0, 1), hpos = mk3(0, 0, 0);
+            float hz = CRT_BIGFLOAT;
+
+            if (pk == PK_SHADOW_CLEAR || pk == PK_SHADOW_BLOCKED) {
+                // end of TraceShadowRay: add the light sample if nothing was in the way (trace.cu:137-143)
+                const uint4 p4 = path4[4], p5 = path4[5];
+                const uint32_t flags = p4.w;
+                if (pk == PK_SHADOW_CLEAR && (flags & 1u)) acc_add(acc_target, mk3(__uint_as_float(p5.x), __uint_as_float(p5.y), __uint_as_float(p5.z)));
+                alive = (flags & 2u) != 0;
+                next_dir = mk3(__uint_as_float(p4.x), __uint_as_float(p4.y), __uint_as_float(p4.z));
+                hpos = mk3(__uint_as_float(p5.w), __uint_as_float(path4[6].x), __uint_as_float(path4[6].y));
+            } else if (pk == PK_CLOSEST_DONE) {
+                const uint4* hit4 = reinterpret_cast<const uint4*>(rec + kRecHit);
+                const uint4 h0 = hit4[0], h1 = hit4[1], h2 = hit4[2], h3 = hit4[3];
+                hz = __uint_as_float(h0.y);
+                uint32_t h_kind = h0.z & 3u;
+                const bool h_front = (h0.z & 4u) != 0;
+                const uint32_t h_node = h0.z >> 3, h_c = h0.w;
+                hpos = mk3(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z));
+                const float h_a = __uint_as_float(h1.w), h_b = __uint_as_float(h2.w);
+                qpos = mk3(__uint_as_float(h2.x), __uint_as_float(h2.y), __uint_as_float(h2.z));
+                qdir = mk3(__uint_as_float(h3.x), __uint_as_float(h3.y), __uint_as_float(h3.z));
+                if (kCount && lane_rank(__ballot(true)) == 0) sect_clock[wave] = __builtin_amdgcn_s_memtime();
+
+                // lights are intersected last, with the ray as the node loop left it (trace.cu:72-78)
+                int hit_light = -1;
+                f3 light_n = mk3(0, 0, 0);
+                for (uint32_t i = 0; i < S.light_count; i++) {
+                    const DevLight Li = S.lights[i];
+                    if (Li.kind != CRT_LIGHT_POINT) continue;
+                    // PointLight::Intersect (scene/lights.cu:36-89)
+                    const f3 lp = ld3(Li.pos);
+                    const f3 o = qpos - lp;
+                    const float a = dot(qdir, qdir);
+                    const float b = dot(2 * qdir, o);
+                    const float c = dot(o, o) - Li.size * Li.size;
+                    const float det = b * b - 4 * a * c;
+                    if (det < 0) continue;
+                    const float sq = sqrtf(det);
+                    const float tf = (-b - sq) / (2 * a);
+                    const float tb = (-b + sq) / (2 * a);
+                    if (tf >= 0) {
+                        if (tf >= hz) continue;
+                        hz = tf;
+                        light_n = normalized(o);
+                        hpos = qpos + tf * qdir;
+                        hit_light = (int)i;
+                        continue;
+                    }
+                    if (tb < 0) continue;
+                    if (tb >= hz) continue;
+                    hz = tb;
+                    light_n = normalized(hpos);      // the previous hit position, as the reference reads it (lights.cu:78)
+                    hpos = qpos + tb * qdir;
+                    hit_light = (int)i;
+                }
+                const bool any = hit_light >= 0 || h_kind != H_NONE;
+                SECT(0);
+
+                if (kPrimary) {
+                    int32_t id = -1, face = -1;
+                    if (hit_light >= 0) id = -2 - hit_light;
+                    else if (any) { id = (int32_t)h_node; if (h_kind == H_MESH) face = (int32_t)tris[h_c].face; }
+                    out_node[pI] = id; out_face[pI] = face; out_t[pI] = hz;
+                } else if (!any) {
+                    const f3 env = tex_env<kCount>(S, qdir, tally);
+                    acc_add(acc_target, contrib * env);
+                    acc_add(acc_normal, contrib * normalized(qdir));
+                    acc_add(acc_albedo, contrib * env);
+                } else if (hit_light >= 0) {
+                    const f3 rad = ld3(S.lights[hit_light].radiance);
+                    acc_add(acc_target, contrib * rad);
+                    acc_add(acc_normal, contrib * light_n);
+                    acc_add(acc_albedo, contrib * rad);
+                } else {
+                    // normal and texture coordinates of the hit (objects.cu:44-50, 126-131, 308-320) and
+                    // Node::FromLocal for the normal (scene/scene.cuh:185-189)
+                    const NodeXf* __restrict__ xf = S.xf + h_node;
+                    f3 n, uvw;
+                    if (h_kind == H_MESH) {
+                        // interpolated vertex normal and texture vertex of the hit triangle (objects.cu:308-320)
+                        const float b1 = h_a, b2 = h_b;
+                        const float b0 = 1 - b2 - b1;
+                        const float4* ap = reinterpret_cast<const float4*>(S.attrs + h_c);
+                        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+                        const uint32_t mesh_flags = xf->flags;
+                        if (!(mesh_flags & kXfHasNormals)) {
+                            const float4* tp = reinterpret_cast<const float4*>(tris + h_c);
+                            const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                            const f3 p0 = mk3(v0.x, v0.y, v0.z);
+                            n = normalized(cross(mk3(v1.x, v1.y, v1.z) - p0, mk3(v2.x, v2.y, v2.z) - p0));
+                        } else {
+                            n = mk3(a0.x, a0.y, a0.z) * b0 + mk3(a0.w, a1.x, a1.y) * b1 + mk3(a1.z, a1.w, a2.x) * b2;
+                        }
+                        if (!(mesh_flags & kXfHasTex)) uvw = mk3(0, 0, 0);
+                        else uvw = mk3(a2.y, a2.z, a2.w) * b0 + mk3(a3.x, a3.y, a3.z) * b1 + mk3(a3.w, a4.x, a4.y) * b2;
+                    } else {
+                        const f3 p = mk3(h_a, h_b, __uint_as_float(h_c));
+                        if (h_kind == H_SPHERE) {
+                            n = p;
+                            uvw = mk3(0.5f * 0.318309f * crtm::det_atan2f(p.y, p.x) + 0.5f,
+                                      0.318309f * crtm::det_asinf(fminf(fmaxf(p.z, -1.0f), 1.0f)) + 0.5f, 0);
+                        } else {
+                            n = mk3(0, 0, 1);
+                            uvw = 0.5f * (p + mk3(1, 1, 0));
+                        }
+                    }
+                    n = xform_normal(xf->itm, n);
+                    SECT(1);
+
+                    const float light_pick = rng_float(rng);
+                    const DevMaterial mtl = S.materials[xf->material_id];
+                    const f3 kD = tex_eval<kCount>(S, mtl.diffuse, uvw, tally);
+                    const f3 kS = tex_eval<kCount>(S, mtl.specular, uvw, tally);
+                    const f3 kT = tex_eval<kCount>(S, mtl.refraction, uvw, tally);
+                    const f3 kE = tex_eval<kCount>(S, mtl.emission, uvw, tally);
+                    SECT(2);
+                    acc_add(acc_normal, contrib * n);
+                    acc_add(acc_albedo, contrib * kD + kE);
+                    acc_add(acc_target, contrib * kE);
+
+                    // lobe probabilities (renderer/shading.cu:17-29 and 122-134)
+                    const float third = 1.0f / 3.0f;
+                    float pD = (kD.x + kD.y + kD.z) * third;
+                    float pS = (kS.x + kS.y + kS.z) * third;
+                    float pT = (kT.x + kT.y + kT.z) * third;
+                    if (pD + pS + pT > CRT_MAX_SURVIVAL) {
+                        const float norm = CRT_MAX_SURVIVAL / (pD + pS + pT);
+                        pD *= norm; pS *= norm; pT *= norm;
+                    }
+                    const float g = mtl.glossiness;
+
+                    // next-event estimation toward one light (trace.cu:112-143).  Ambient and directional
+                    // lights produce no sample and zero weight, so nothing is traced for them; with no
+                    // light at all (where the reference reads a null light) no sample is taken either.
+                    bool nee_valid = false;
+                    f3 nee = mk3(0, 0, 0);
+                    if (S.light_count > 0) {
+                        const int light_id = crtm::f2i_sat(light_pick * (float)S.light_count);
+                        const DevLight Ls = S.lights[light_id];
+                        if (Ls.kind == CRT_LIGHT_POINT) {
+                            // PointLight::GenerateSample (scene/lights.cu:10-34)
+                            const f3 lp = ld3(Ls.pos);
+                            const f3 Ldir = normalized(hpos - lp);
+                            const float x = rng_float(rng);
+                            const float phi = rng_float(rng) * 2 * F_PI;
+                            const float cos_theta = 1 - x;
+                            const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+                            f3 a, b;
+                            orthonormals(Ldir, a, b);
+                            float sin_phi, cos_phi;
+                            crtm::det_sincosf(phi, sin_phi, cos_phi);
+                            const f3 ln = Ldir * cos_theta + a * sin_theta * cos_phi + b * sin_theta * sin_phi;
+                            const f3 tgt = lp + ln * Ls.size;
+                            const f3 ldir = normalized(tgt - hpos);
+                            const float d2 = lengthsq(tgt - hpos);
+                            const float cos_theta_l = dot(ldir, -normalized(tgt - lp));
+                            const float l_prob = d2 / (2 * F_PI * Ls.size * Ls.size * cos_theta_l);
+                            const f3 l_mult = ld3(Ls.radiance);
+                            sdist = sqrtf(d2);
+                            // Material::GetSampleInfo (renderer/shading.cu:116-150)
+                            float b_prob = 0.0f;
+                            f3 b_mult = mk3(0, 0, 0);
+                            const float ndl = dot(n, ldir);
+                            if (ndl >= 0) {
+                                b_prob += pD * (ndl > 0 ? OVERPI : 0);
+                                b_mult += kD * OVERPI * ndl;
+                                const f3 rn = normalized(v + ldir);
+                                const float ndh = dot(n, rn);
+                                b_prob += pS * (g + 1) * 0.5f * OVERPI * crtm::det_powf(ndh, g + 1);
+                                b_mult += kS * (g + 2) * 0.125f * OVERPI * crtm::det_powf(ndh, g);
+                            }
+                            const float denom = l_prob * l_prob + b_prob * b_prob;
+                            if (denom > CRT_F_EPS && l_prob > CRT_F_EPS) {
+                                const float pop = l_prob / denom;
+                                nee = contrib * l_mult * b_mult * pop;
+                                nee_valid = true;
+                            }
+                            // TraceShadowRay prologue (trace.cu:160-162)
+                            spos = hpos; sdir = ldir;
+                            spos += sdir * CRT_BIAS + n * CRT_BIAS;
+                            want_shadow = true;
+                        }
+                    }
+
+                    SECT(3);
+                    // Material::GenerateSample (renderer/shading.cu:11-113)
+                    f3 kA = mk3(1, 1, 1);
+                    if (!h_front) {
+                        const f3 e = ld3(mtl.absorption) * -hz;
+                        kA = mk3(crtm::det_expf(e.x), crtm::det_expf(e.y), crtm::det_expf(e.z));
+                    }
+                    const float p = rng_float(rng);
+                    f3 ndir = mk3(0, 0, 0), n_mult = mk3(0, 0, 0);
+                    float n_prob = 0;
+                    bool sampled = true;
+                    if (p < pD) {
+                        const float x = rng_float(rng);
+                        const float phi = rng_float(rng) * 2 * F_PI;
+                        const float cos_theta = 1 - x;
+                        const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+                        f3 u, w;
+                        orthonormals(n, u, w);
+                        float sin_phi, cos_phi;
+                        crtm::det_sincosf(phi, sin_phi, cos_phi);
+                        ndir = n * cos_theta + u * sin_theta * cos_phi + w * sin_theta * sin_phi;
+                        n_prob = pD * OVERPI;
+                        n_mult = kA * kD * OVERPI * dot(n, ndir);
+                    } else {
+                        const f3 gln = glossy_normal(n, g, rng);
+                        if (p < pD + pS) {
+                            ndir = reflect(v, gln);
+                            const float pw = crtm::det_powf(dot(gln, n), g);
+                            n_prob = pS * (g + 1) * 0.125f * OVERPI * pw;
+                            n_mult = kA * kS * (g + 2) * 0.125f * OVERPI * pw;
+                        } else if (p < pD + pS + pT) {
+                            const float eta_i = h_front ? 1 : mtl.ior;
+                            const float eta_o = h_front ? mtl.ior : 1;
+                            const f3 h = h_front ? gln : -gln;
+                            bool tir = false;
+                            ndir = transmit(v, h, eta_i, eta_o, tir);
+                            const float f_0 = crtm::det_powf((eta_i - eta_o) / (eta_i + eta_o), 2);
+                            const float cos_theta = dot(v, h);
+                            float f_theta = f_0 + (1 - f_0) * crtm::det_powf(1 - cos_theta, 5);
+                            f_theta = fminf(fmaxf(f_theta, 0.0f), 1.0f);
+                            if (!tir) {
+                                if (rng_float(rng) >= f_theta) {
+                                    n_prob = pT * (1 - f_theta);
+                                    n_mult = kA * kT * (1 - f_theta);
+                                } else {
+                                    ndir = reflect(v, h);
+                                    n_prob = pT * f_theta;
+                                    n_mult = kA * kT * f_theta;
+                                }
+                            } else {
+                                n_prob = pT;
+                                n_mult = kA * kT;
+                            }
+                        } else {
+                            sampled = false;
+                        }
+                    }
+                    // the path continues unless the sample died, its probability vanished or the safety bound hit
+                    if (sampled) {
+                        next_dir = ndir;
+                        if (!(n_prob <= CRT_F_EPS)) {
+                            contrib *= n_mult * (1.0f / n_prob);
+                            alive = ++segments < CRT_MAX_SEGMENTS;
+                        }
+                    }
+                    if (want_shadow) {
+                        // parked until the shadow query comes back: continuation direction, light sample, hit position
+                        path4[4] = uint4{__float_as_uint(next_dir.x), __float_as_uint(next_dir.y), __float_as_uint(next_dir.z), (nee_valid ? 1u : 0u) | (alive ? 2u : 0u)};
+                        path4[5] = uint4{__float_as_uint(nee.x), __float_as_uint(nee.y), __float_as_uint(nee.z), __float_as_uint(hpos.x)};
+                        rec[kRecPath + 24] = __float_as_uint(hpos.y); rec[kRecPath + 25] = __float_as_uint(hpos.z);
+                    }
+                }
+            }
+
+            SECT(4);
+            // ---- what comes next for this pixel
+            f3 rpos, rdir;
+            float rlimit;
+            bool rshadow;
+            if (want_shadow) {
+                tally.shadow_rays++;
+                rpos = spos; rdir = sdir; rlimit = sdist; rshadow = true;
+                result = R_RAY;
+            } else {
+                bool have_ray = true;
+                rpos = hpos; rdir = next_dir;
+                if (alive) {
+                    // continue from the hit position (trace.cu:150-156)
+                } else if (pk != PK_NEW_PATH && ++sample >= samples) {
+                    have_ray = false;
+                    if (!kPrimary && P.tile_cost) atomicMax(P.tile_cost + (fresh ? tile : rec[kRecPath + 26]), cost);
+                } else {
+                    // a new path: camera ray (trace.cu:26-38)
+                    const uint32_t pY = pI / S.width, pX = pI - pY * S.width;
+                    camera_ray(S, pX, pY, rng, rpos, rdir);
+                    contrib = mk3(1, 1, 1) * inv_samples;
+                    segments = 0;
+                    TALLY(paths);
+                }
+                if (have_ray) {
+                    // TraceThroughScene prologue (renderer/trace.cu:44-50)
+                    v = -normalized(rdir);
+                    rpos = rpos + rdir * CRT_BIAS;
+                    rlimit = CRT_BIGFLOAT;
+                    rshadow = false;
+                    tally.closest_rays++;
+                    result = R_RAY;
+                } else {
+                    rlimit = 0; rshadow = false;
+                    result = R_REFETCH;
+                }
+            }
+            path4[0] = uint4{rng.d, rng.v0, rng.v1, rng.v2};
+            path4[1] = uint4{rng.v3, rng.v4, __float_as_uint(contrib.x), __float_as_uint(contrib.y)};
+            path4[2] = uint4{__float_as_uint(contrib.z), __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+            path4[3] = uint4{(uint32_t)sample, segments, cost + 1u, pI};
+            if (fresh) rec[kRecPath + 26] = tile;
+            if (result == R_RAY) {
+                // one pass over the node boxes for the query the slot is about to start
+                unsigned long long mask = ~0ull;
+                uint32_t node = 0;
+                if (S.scan_mask) {
+                    mask = scan_candidates(S, pairs, rpos, rdir, rlimit, rshadow);
+                    if (by_mask) node = mask ? (uint32_t)__ffsll((long long)mask) - 1u : node_count;
+                }
+                const f3 rinv = recip3(rdir);
+                uint4* ray4 = reinterpret_cast<uint4*>(rec + kRecRay);
+                ray4[0] = uint4{__float_as_uint(rpos.x), __float_as_uint(rpos.y), __float_as_uint(rpos.z), __float_as_uint(rlimit)};
+                ray4[1] = uint4{__float_as_uint(rdir.x), __float_as_uint(rdir.y), __float_as_uint(rdir.z), rshadow ? 1u : 0u};
+                ray4[2] = uint4{__float_as_uint(rinv.x), __float_as_uint(rinv.y), __float_as_uint(rinv.z), node};
+                ray4[3] = uint4{(uint32_t)mask, (uint32_t)(mask >> 32), 0u, 0u};
+            } else {
+                rec[kRecHit] = PK_FETCH;
+            }
+            SECT(5);
+            return result;
+        };
+
+        // ---- the loop of a shading wave: take up to 64 slots, shade them, hand each one on
+        uint32_t patience = 0;
+        for (;;) {
+            // Full turns when the traversal lanes have queries in reserve; while their queue runs low a partial turn
+            // is better than letting them idle.
+            uint32_t min_take = 1;
+            {
+                const uint32_t ready = lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head);
+                if (ready >= S.serve_low_water && patience < S.serve_patience) min_take = S.serve_batch_min;
+            }
+            uint32_t slot = 0;
+            const bool have = queue_pop(&ctl.shade_head, &ctl.shade_tail, shade_ring, true, min_take, n_slots, slot, &ctl.abort);
+            if (__ballot(have) == 0) {
+                patience++;
+                if (!idle_wait()) break;
+                continue;
+            }
+            patience = 0; idle_polls = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            unsigned long long t_start = 0;
+            if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.turns[3]++; tally.lanes[3] += have; }
+            const uint32_t result = serve(have, slot);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            queue_push(&ctl.ray_tail, ray_ring, result == R_RAY, slot);
+            queue_push(&ctl.shade_tail, shade_ring, result == R_REFETCH, slot);
+            const unsigned long long retired = __ballot(result == R_RETIRE);
+            if (retired != 0 && lane_rank(__ballot(true)) == 0) atomicSub(&ctl.live, (uint32_t)__popcll(retired));
+            if (kCount) tally.cycles[3] += __builtin_amdgcn_s_memtime() - t_start;
         }
-        if (kCount) {
-            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
-            switch (best) { case S_BOX: tally.cycles[0] += dt; break; case S_LEAF: tally.cycles[1] += dt; break; case S_XFORM: tally.cycles[2] += dt; break; case S_PATH: tally.cycles[3] += dt; break; default: tally.cycles[4] += dt; break; }
-        }
+#undef SECT
     }
 
     // ---- counters: one atomic per wave and field
@@ -1094,9 +1331,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         c_tx = wave_sum(tally.texel_quads);
         c_sc = wave_sum(tally.scan_checks); c_sv = wave_sum(tally.scan_violations);
     }
-    if (!kPrimary && (threadIdx.x & 63u) == 0) {
-        atomicAdd(&stats->closest_rays, c_closest);
-        atomicAdd(&stats->shadow_rays, c_shadow);
+    if (!kPrimary && (tid & 63u) == 0) {
+        if (c_closest) atomicAdd(&stats->closest_rays, c_closest);
+        if (c_shadow) atomicAdd(&stats->shadow_rays, c_shadow);
         if (kCount) {
             atomicAdd(&stats->paths, c_paths); atomicAdd(&stats->node_box_tests, c_nb); atomicAdd(&stats->node_enters, c_ne);
             atomicAdd(&stats->bvh_interior, c_bi); atomicAdd(&stats->bvh_leaves, c_bl); atomicAdd(&stats->tri_tests, c_tt);
@@ -1105,17 +1342,18 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             atomicAdd(&stats->scan_checks, c_sc); atomicAdd(&stats->scan_violations, c_sv);
         }
     }
+    if (lds_ld(&ctl.abort) != 0 && tid == 0) atomicAdd(&stats->errors, 1ull);
     if (kCount && !kPrimary) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const unsigned long long t = wave_sum(tally.turns[k]), l = wave_sum(tally.lanes[k]);
-            if ((threadIdx.x & 63u) == 0) { atomicAdd(&stats->sched_turns[k], t / 64); atomicAdd(&stats->sched_lanes[k], l); atomicAdd(&stats->sched_cycles[k], tally.cycles[k]); }
+            if ((tid & 63u) == 0) { atomicAdd(&stats->sched_turns[k], t / 64); atomicAdd(&stats->sched_lanes[k], l); atomicAdd(&stats->sched_cycles[k], tally.cycles[k]); }
         }
         for (int k = 0; k < 6; k++)
-            if ((threadIdx.x & 63u) == 0) atomicAdd(&stats->path_cycles[k], path_sections[(threadIdx.x >> 6) * 8 + k]);
-        if ((threadIdx.x & 63u) == 0) {
+            if ((tid & 63u) == 0) atomicAdd(&stats->path_cycles[k], path_sections[wave * 8 + k]);
+        if ((tid & 63u) == 0) {
             const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-            const unsigned long long t_kernel = wave_clock[(threadIdx.x >> 6) * 2], t_dry = wave_clock[(threadIdx.x >> 6) * 2 + 1];
+            const unsigned long long t_kernel = wave_clock[wave * 2], t_dry = wave_clock[wave * 2 + 1];
             atomicAdd(&stats->path_cycles[6], t_end - t_kernel);                       // wave lifetime
             atomicAdd(&stats->path_cycles[7], t_dry ? t_end - t_dry : 0ull);           // of which after the queue ran dry
         }

@@ -18,6 +18,17 @@ namespace crt {
 static thread_local std::string g_host_error;
 void set_host_error(const std::string& msg) { g_host_error = msg; }
 
+uint32_t knob_value(const char* text, uint32_t fallback, uint32_t lo, uint32_t hi) {
+    if (!text || !*text) return fallback;
+    uint64_t v = 0;
+    for (const char* c = text; *c; c++) {
+        if (*c < '0' || *c > '9') return fallback;
+        v = v * 10 + (uint64_t)(*c - '0');
+        if (v > 0xffffffffull) return fallback;
+    }
+    return (v < lo || v > hi) ? fallback : (uint32_t)v;
+}
+
 void HostScene::refresh_views() {
     texture_views.resize(textures.size());
     for (size_t i = 0; i < textures.size(); i++) {
@@ -167,5 +178,7 @@ int crt_png_read_rgb8(const char* path, uint8_t** rgb, uint32_t* width, uint32_t
 }
 
 void crt_free(void* p) { free(p); }
+
+uint32_t crt_knob_value(const char* text, uint32_t fallback, uint32_t lo, uint32_t hi) { return crt::knob_value(text, fallback, lo, hi); }
 
 }  // extern "C"

@@ -76,5 +76,7 @@ bool bvh_build(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
                const float* box_min, const float* box_max, HostBvh& out, std::string& err);
 
 void set_host_error(const std::string& msg);
+// numeric environment override: the value of `text` if it is a whole decimal number in [lo, hi], else `fallback`
+uint32_t knob_value(const char* text, uint32_t fallback, uint32_t lo, uint32_t hi);
 
 }  // namespace crt

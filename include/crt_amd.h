@@ -284,8 +284,8 @@ typedef struct crt_stats {
     uint64_t plane_tests;
     uint64_t texel_quads;      /* bilinear texture evaluations */
     /* scheduler detail of the trace kernel (counted build): how often each operation
-     * (0 box, 1 triangle, 2 transform, 3 path, 4 fetch) was executed by a
-     * wave, and how many lanes took part in total */
+     * (0 box, 1 triangle, 2 transform, 3 shading, 4 exchange of results for new queries,
+     * 5 pixel fetch) was executed by a wave, and how many lanes took part in total */
     uint64_t sched_turns[8];
     uint64_t sched_lanes[8];
     uint64_t sched_cycles[8];   /* shader clock cycles waves spent in turns of each operation */
@@ -294,6 +294,8 @@ typedef struct crt_stats {
                                    lifetimes, [7] the part of them after the pixel queue ran dry */
     uint64_t scan_checks;       /* scene-node boxes the counted pass found hit, each checked against the */
     uint64_t scan_violations;   /* candidate mask the plain pass scans by; a violation would be a parity bug */
+    uint64_t errors;            /* waves of the trace kernel that gave up waiting on their block's queues: 0 unless
+                                   the kernel's hand-off protocol failed (crt_get_stats then returns an error) */
 } crt_stats;
 
 int crt_get_stats(crt_ctx* ctx, crt_stats* out);
@@ -314,6 +316,12 @@ int crt_rng_selftest(crt_ctx* ctx, const uint32_t* seeds, const uint32_t* subseq
  * on n host floats on the GPU. */
 int crt_math_selftest(crt_ctx* ctx, int fn, const float* x, const float* y, uint32_t n,
                       float* out);
+
+/* How the library reads a numeric environment override (CRT_SCHED_BOX_MIN,
+ * CRT_TRAV_WAVES, ...): the decimal value of `text` when it is a whole number
+ * inside [lo, hi], otherwise `fallback` (NULL, empty, non-numeric or out of
+ * range text never reaches the kernels). */
+uint32_t crt_knob_value(const char* text, uint32_t fallback, uint32_t lo, uint32_t hi);
 
 /* Milliseconds the most recent crt_render_pass kernel took, measured with HIP
  * events on its stream (blocks until it has finished). */

@@ -34,7 +34,18 @@ def test_struct_sizes_match_the_c_side():
     assert ctypes.sizeof(capi.Node) == 136
     assert ctypes.sizeof(capi.Material) == 36
     assert ctypes.sizeof(capi.Light) == 32
-    assert ctypes.sizeof(capi.Stats) == 96 + 256 + 16
+    assert ctypes.sizeof(capi.Stats) == 96 + 256 + 16 + 8
+
+
+def test_environment_overrides_are_range_checked():
+    """A typo in a CRT_* scheduler override must never reach the kernels: anything that is not a whole number inside
+    the accepted range reads as the default."""
+    k = capi.lib().crt_knob_value
+    assert k(None, 12, 1, 64) == 12 and k(b"", 12, 1, 64) == 12
+    assert k(b"16", 12, 1, 64) == 16 and k(b"1", 12, 1, 64) == 1 and k(b"64", 12, 1, 64) == 64
+    for bad in (b"0", b"65", b"-3", b"abc", b"1e3", b" 8", b"8 ", b"99999999999999999999", b"4294967296"):
+        assert k(bad, 12, 1, 64) == 12, bad
+    assert k(b"0", 5, 0, 10) == 0
 
 
 def test_error_paths_without_compute(tmp_path):

@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
-"""Time the trace kernel on the benchmark scene for a grid of scheduler thresholds."""
-import itertools, os, sys
+"""Time the trace kernel on the benchmark scene for a list of knob settings.
+
+usage: knob_sweep.py SPP "NAME=V,NAME=V" "NAME=V" ...   (names without the CRT_ prefix; "" = defaults)"""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import cudaraytracing_amd as crt
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-s = crt.Scene.load_file(os.path.join(ROOT, "tests/golden/scenes/final_frame0042.crtscene")); s.set_resolution(1920, 1080)
-boxes = [int(v) for v in os.environ.get("SWEEP_BOX", "16,24,32").split(",")]
-specials = [int(v) for v in os.environ.get("SWEEP_SPECIAL", "6,8,12").split(",")]
-heavies = [int(v) for v in os.environ.get("SWEEP_HEAVY", "1,24,32,40,48").split(",")]
-for b, sp, h in itertools.product(boxes, specials, heavies):
-    os.environ["CRT_SCHED_BOX_MIN"] = str(b); os.environ["CRT_SCHED_SPECIAL_MIN"] = str(sp); os.environ["CRT_SCHED_HEAVY_MIN"] = str(h)
+scene = os.environ.get("SWEEP_SCENE", "final_frame0042")
+w, h = (int(v) for v in os.environ.get("SWEEP_SIZE", "1920x1080").split("x"))
+s = crt.Scene.load_file(os.path.join(ROOT, f"tests/golden/scenes/{scene}.crtscene")); s.set_resolution(w, h)
+KNOBS = ("SCHED_BOX_MIN", "SCHED_SPECIAL_MIN", "SCHED_EXCHANGE_MIN", "TRAV_WAVES", "SLOTS", "SERVE_BATCH_MIN", "SERVE_LOW_WATER", "SERVE_PATIENCE", "SERVE_PRIORITY")
+for spec in sys.argv[2:] or [""]:
+    for k in KNOBS:
+        os.environ.pop("CRT_" + k, None)
+    for kv in filter(None, spec.split(",")):
+        k, v = kv.split("=")
+        assert k in KNOBS, k
+        os.environ["CRT_" + k] = v
     ctx = crt.Context(0); ctx.upload(s)
     ctx.render_pass(0, spp); ctx.clear(); ctx.render_pass(0, spp)
-    print(f"box {b:3d} special {sp:3d} heavy {h:3d}  kernel ms {ctx.last_kernel_ms():8.2f}", flush=True)
-    del ctx
+    a = ctx.last_kernel_ms()
+    ctx.clear(); ctx.render_pass(0, spp)
+    print(f"{spec or 'defaults':60s} kernel ms {a:8.2f} {ctx.last_kernel_ms():8.2f}", flush=True)
+    ctx.stats()          # raises if the kernel reported a protocol error
+    ctx.close()

@@ -14,7 +14,7 @@ st = ctx.stats(); print(st)
 rays = st["closest_rays"] + st["shadow_rays"]
 tot = 0
 sched = ctx.schedule_stats()
-cyc_total = sum(c for _, _, c in sched.values())
+cyc_total = sum(c for _, _, c in sched.values())  # operations 0..5
 for k, (turns, lanes, cyc) in sched.items():
     tot += turns
     print(f"{k:9s} turns {turns:12d} lanes/turn {lanes / max(turns, 1):6.2f}  turns per 64 rays {turns * 64 / rays:8.2f}  lanes per ray {lanes / rays:6.2f}  cycles/turn {cyc / max(turns, 1):8.0f}  share {100 * cyc / max(cyc_total, 1):5.1f}%")
@@ -24,7 +24,10 @@ import ctypes
 from cudaraytracing_amd import _capi as capi
 st2 = capi.Stats(); capi.lib().crt_get_stats(ctx._h, ctypes.byref(st2))
 pt = sched["path"][0]
-print("PATH sections cycles/turn: lights %.0f  attrs %.0f  textures %.0f  light-sample %.0f  bsdf %.0f  next-ray %.0f" % tuple(st2.path_cycles[k] / max(pt, 1) for k in range(6)))
-print("at path turns, lanes per turn: done %.1f  waiting to fetch %.1f  box %.1f" % tuple(st2.sched_lanes[k] / max(pt, 1) for k in (5, 6, 7)))
-print("wave lifetime after the queue ran dry: %.1f %%" % (100.0 * st2.path_cycles[7] / max(st2.path_cycles[6], 1)))
+print("shading sections cycles/turn: lights %.0f  attrs %.0f  textures %.0f  light-sample %.0f  bsdf %.0f  next-ray %.0f" % tuple(st2.path_cycles[k] / max(pt, 1) for k in range(6)))
+votes = max(st2.sched_turns[6], 1)
+print("traversal lanes at a vote: idle %.1f  waiting to post %.1f" % (st2.sched_lanes[6] / votes, st2.sched_lanes[7] / votes))
+print("queue fill at a vote: ready queries %.1f  slots waiting for shading %.1f" % (st2.sched_cycles[6] / votes, st2.sched_cycles[7] / votes))
+print("exchange turns: lanes that wanted a query %d, got one %d" % (st2.sched_lanes[4], st2.sched_cycles[5]))
+print("wave lifetime after the pixel queue ran dry (shading waves): %.1f %%" % (100.0 * st2.path_cycles[7] / max(st2.path_cycles[6], 1)))
 ctx.clear(); ctx.render_pass(0, spp); print("plain kernel ms", ctx.last_kernel_ms())
