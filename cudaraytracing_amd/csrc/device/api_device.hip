@@ -33,6 +33,7 @@ struct crt_ctx {
     bool order_valid = false;
     bool deep = false;                         // BVH deeper than the LDS stack: kDeep kernels
     uint32_t stack_overflow = 0;               // stack entries per thread kept in the side buffer
+    bool interleave = false;                   // tile order: expensive and cheap tiles alternate
     bool no_balance = false;                   // CRT_NO_BALANCE=1: always hand tiles out in storage order
     DevStats* stats = nullptr;
     std::map<int, uint32_t*> jumps;            // pass -> 160 x 5 jump matrix on the device
@@ -521,6 +522,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.serve_patience = crt::knob_value(getenv("CRT_SERVE_PATIENCE"), 64, 0, 1u << 20);
     S.serve_priority = crt::knob_value(getenv("CRT_SERVE_PRIORITY"), 1, 0, 1);
     S.watchdog_ticks = 100000000ull * crt::knob_value(getenv("CRT_WATCHDOG_SECONDS"), 30, 1, 3600);
+    ctx->interleave = crt::knob_value(getenv("CRT_TILE_INTERLEAVE"), 0, 0, 1) != 0;
     { const char* e = getenv("CRT_NO_BALANCE"); ctx->no_balance = e && atoi(e) != 0; }
     if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
         (rc = upload(ctx, attrs, &S.attrs)) || (rc = upload(ctx, materials, &S.materials)) ||
@@ -639,7 +641,7 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], stream));
     ctx->launches++;
     if (balance) {
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ctx->tile_cost, ctx->tile_order, tiles);
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ctx->tile_cost, ctx->tile_order, tiles, ctx->interleave ? 1 : 0);
         HIP_TRY(ctx, hipGetLastError());
         ctx->order_valid = true;
     }

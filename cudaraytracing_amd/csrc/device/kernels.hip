@@ -31,6 +31,8 @@
 
 #include <float.h>
 
+#include <type_traits>
+
 #include "dev_scene.h"
 
 namespace crt {
@@ -343,18 +345,19 @@ DEV void acc_add(float* __restrict__ p, f3 v) {
 
 // ------------------------------------------------------------------ per-lane state
 // Operation a traversal lane needs next.
-//   BOX    slab-test one box-pair record (scene-node scan or BVH interior node)
+//   BOX    slab-test the two children of a BVH interior node (one box-pair record)
 //   LEAF   test the next one or two triangles of the pending leaf
-//   XFORM  enter a scene node (world -> local, sphere / plane test or BVH root) or leave a mesh
+//   NODE   one step of the scene-node scan: leave the mesh just walked, test the next node's box, enter the node
+//          (world -> local, sphere / plane test or BVH root)
 //   POST   the query has ended: its result has to be handed to the shading waves
 //   IDLE   the lane has no query: it takes the next one from the block's ray queue
-enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_XFORM = 2, S_POST = 3, S_IDLE = 4 };
+enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_NODE = 2, S_POST = 3, S_IDLE = 4 };
 enum : uint32_t { H_NONE = 0, H_SPHERE = 1, H_PLANE = 2, H_MESH = 3 };
 // why a slot is in the shading queue
 enum : uint32_t { PK_NEW_PATH = 0, PK_CLOSEST_DONE = 1, PK_SHADOW_CLEAR = 2, PK_SHADOW_BLOCKED = 3, PK_FETCH = 4 };
 // what a shading turn decided for a slot
 enum : uint32_t { R_NONE = 0, R_RAY = 1, R_REFETCH = 2, R_RETIRE = 3 };
-constexpr uint32_t kPendExit = 0x20000000u;     // XFORM: leave the mesh of node `entered`
+constexpr uint32_t kPendExit = 0x20000000u;     // NODE: leave the mesh of node `entered` first
 
 struct Lane {
     uint32_t slot;                  // pixel slot whose query this lane is running
@@ -374,7 +377,7 @@ struct Lane {
     uint32_t cur;                   // BVH record to expand
     uint32_t sp;                    // LDS stack height
     uint32_t entered;               // scene node whose mesh is being traversed
-    uint32_t pend;                  // LEAF: remaining leaf range; XFORM: node | kind << 30, or kPendExit
+    uint32_t pend;                  // LEAF: remaining leaf range; NODE: kPendExit when a mesh has to be left first
     bool shadow, trav, mesh_hit;
     // closest hit so far; normal / texture coordinates are derived from (h_*) when the query ends
     float hz;
@@ -398,13 +401,15 @@ struct Lane {
 // lanes full while any one pixel still sees its operations in the reference's order.  Both queues are rings of
 // slot numbers in LDS; an entry carries the lap number of its position, so a consumer that has claimed a position
 // knows when the producer's write has landed without a second counter.
-constexpr uint32_t kQueueLog = 11, kQueueSize = 1u << kQueueLog;      // ring positions; slots per block <= kQueueSize
+constexpr uint32_t kQueueLog = 10, kQueueSize = 1u << kQueueLog;      // ring positions; slots per block <= kQueueSize
 constexpr uint32_t kSlotWords = 64;
 constexpr uint32_t kRecRay = 0, kRecHit = 16, kRecPath = 32;
 constexpr uint32_t kMaxWaves = 16;
 
 struct BlockCtl {
-    uint32_t shade_head, shade_tail;    // slots waiting for a shading lane
+    // slots waiting for a shading lane, in two queues so that a shading turn is all of one kind: [0] a closest-hit query
+    // has ended (the full shading code), [1] a shadow query has ended or the slot needs a pixel (little code)
+    uint32_t shade_head[2], shade_tail[2];
     uint32_t ray_head, ray_tail;        // slots whose next query waits for a traversal lane
     uint32_t live;                      // slots that still have a pixel or may get one
     uint32_t abort;                     // a wave gave up waiting (a protocol error): every wave leaves
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                                                              float* __restrict__ out_t, uint32_t* slot_mem) {
     extern __shared__ uint32_t lds[];
     __shared__ BlockCtl ctl;
-    __shared__ uint32_t shade_ring[kQueueSize], ray_ring[kQueueSize];
+    __shared__ uint32_t shade_ring[2][kQueueSize], ray_ring[kQueueSize];
     __shared__ unsigned long long sect_clock[kMaxWaves], path_sections[kMaxWaves * 8], wave_clock[kMaxWaves * 2];      // counted build only
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6;
@@ -491,10 +496,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     if (kCount) for (uint32_t i = tid; i < kMaxWaves * 8; i += CRT_BLOCK) path_sections[i] = 0;
     for (uint32_t i = tid; i < kQueueSize; i += CRT_BLOCK) {
         ray_ring[i] = 0;
-        shade_ring[i] = i < n_slots ? ((1u << kQueueLog) | i) : 0u;
+        shade_ring[0][i] = 0;
+        shade_ring[1][i] = i < n_slots ? ((1u << kQueueLog) | i) : 0u;
     }
     for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
-    if (tid == 0) { ctl.shade_head = 0; ctl.shade_tail = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; }
+    if (tid == 0) { ctl.shade_head[0] = 0; ctl.shade_tail[0] = 0; ctl.shade_head[1] = 0; ctl.shade_tail[1] = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -552,14 +558,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         auto query_done = [&]() -> uint32_t { L.pk = L.shadow ? PK_SHADOW_CLEAR : PK_CLOSEST_DONE; return S_POST; };
         auto shadow_blocked = [&]() -> uint32_t { L.pk = PK_SHADOW_BLOCKED; return S_POST; };
         auto first_candidate = [&]() -> uint32_t { return L.mask ? (uint32_t)__ffsll((long long)L.mask) - 1u : node_count; };
-        auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_BOX : query_done(); };
+        auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_NODE : query_done(); };
 
         // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
         // (MeshObject::Traverse / TraverseShadow loop heads, scene/objects.cu:184-196, 231-242)
         auto resolve = [&](bool have_next, uint32_t next_ref, float next_t) -> uint32_t {
             for (;;) {
                 if (!have_next) {
-                    if (L.sp == 0) { L.pend = kPendExit; return S_XFORM; }
+                    if (L.sp == 0) { L.pend = kPendExit; return S_NODE; }
                     L.sp--;
                     stack_get(L.sp, next_ref, next_t);
                 }
@@ -573,11 +579,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             }
         };
 
-        // ---- BOX: one box-pair record, two slab tests: scene-node scan (trace.cu:51-68, 166-193) or
-        // BVH interior node (objects.cu:198-218, 244-264)
+        // ---- BOX: one BVH interior node, i.e. the slab tests of its two children (objects.cu:198-218, 244-264)
         auto op_box = [&]() -> uint32_t {
-            const uint32_t rec_idx = L.trav ? L.cur : L.node;
-            const float4* rp = reinterpret_cast<const float4*>(pairs + rec_idx);
+            const float4* rp = reinterpret_cast<const float4*>(pairs + L.cur);
             const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
             const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
             float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
@@ -586,64 +590,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const bool hitB = slab(f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, L.qpos(), L.qinv, L.limit, dB);
             if (hitA) tA = dA;
             if (hitB) tB = dB;
-            if (L.trav) {
-                TALLY(bvh_interior);
-                // both children go on the stack, far one first (objects.cu:216-218); when neither box is hit the
-                // slot above the top is written and left unused, so one copy of the pop loop serves both cases
-                const bool any = hitA || hitB;
-                const bool a_near = tA <= tB;
-                stack_put(L.sp, a_near ? ref_b : ref_a, fmaxf(tA, tB));
-                L.sp += any ? 1u : 0u;
-                return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
-            }
-            // scan: node `node` is half A, node + 1 is half B.  Closest hit enters a node whose box is
-            // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
-            // subtree of a node with an object whose box it misses (trace.cu:171-185).
-            // (The half after the last node of an odd list is a dummy without an object and with an empty box.)
-            const uint32_t kind_a = node_ref_kind(ref_a), kind_b = node_ref_kind(ref_b);
-            const uint32_t after_a = node_ref_after(ref_a), after_b = node_ref_after(ref_b);
-            const bool sh = L.shadow;
-            if (by_mask) {
-                // Scan by candidates: half A is the lowest candidate, half B is looked at when it is one too.  Nodes in
-                // between were certain misses; a candidate object node that a shadow ray misses takes its subtree along.
-                const uint32_t i = L.node;
-                const bool enter_a = hitA & (sh | (tA < L.hz));
-                unsigned long long m = L.mask & ~(1ull << i);
-                if (sh & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << i) - 1ull);
-                const bool cand_b = !enter_a & (i < 63u) & (((m >> ((i + 1u) & 63u)) & 1ull) != 0);
-                const bool enter_b = cand_b & hitB & (sh | (tB < L.hz));
-                if (cand_b) {
-                    m &= ~(2ull << i);
-                    if (sh & !hitB) m &= ~(((1ull << (after_b & 63u)) - 1ull) | (after_b >= 64u ? ~0ull : 0ull)) | ((4ull << i) - 1ull);
-                }
-                L.mask = m;
-                if (enter_a | enter_b) {
-                    L.pend = enter_a ? (i | (kind_a << 30)) : ((i + 1u) | (kind_b << 30));
-                    return S_XFORM;
-                }
-                L.node = first_candidate();
-                return after_scan();
-            }
-            const bool obj_a = kind_a != CRT_OBJ_NONE, obj_b = kind_b != CRT_OBJ_NONE;
-            const bool enter_a = obj_a & hitA & (sh | (tA < L.hz));
-            const bool jump_a = sh & obj_a & (after_a != L.node + 1);            // shadow ray past a missed subtree
-            const bool look_b = !(enter_a | jump_a);
-            const bool enter_b = look_b & obj_b & hitB & (sh | (tB < L.hz));
-            if (kCount) {
-                tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b & obj_b) ? 1u : 0u);
-                // every box the full scan finds hit must be a candidate of the mask the plain kernels scan by
-                if (S.scan_mask) {
-                    const bool chk_a = obj_a & hitA, chk_b = look_b & obj_b & hitB;
-                    tally.scan_checks += (chk_a ? 1u : 0u) + (chk_b ? 1u : 0u);
-                    tally.scan_violations += ((chk_a && !((L.mask >> (L.node & 63u)) & 1ull)) ? 1u : 0u) + ((chk_b && !((L.mask >> ((L.node + 1u) & 63u)) & 1ull)) ? 1u : 0u);
-                }
-            }
-            if (enter_a | enter_b) {
-                L.pend = enter_a ? (L.node | (kind_a << 30)) : ((L.node + 1) | (kind_b << 30));
-                return S_XFORM;
-            }
-            L.node = jump_a ? after_a : ((sh & obj_b) ? after_b : L.node + 2);
-            return after_scan();
+            TALLY(bvh_interior);
+            // both children go on the stack, far one first (objects.cu:216-218); when neither box is hit the
+            // slot above the top is written and left unused, so one copy of the pop loop serves both cases
+            const bool any = hitA || hitB;
+            const bool a_near = tA <= tB;
+            stack_put(L.sp, a_near ? ref_b : ref_a, fmaxf(tA, tB));
+            L.sp += any ? 1u : 0u;
+            return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
         };
 
         // ---- LEAF: the next two triangles of the pending leaf, one after the other (IntersectTriangle /
@@ -701,69 +655,132 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             return resolve(false, 0, 0);
         };
 
-        // ---- XFORM: enter a scene node (Node::ToLocal, then the sphere / plane test in place or the
-        // start of a BVH walk: trace.cu:61-66, 188-191; objects.cu:7-159) or leave a mesh (world
-        // position of its hit, Node::FromLocal for the ray: trace.cu:64-66, 191)
-        auto op_xform = [&]() -> uint32_t {
-            const bool leaving = L.pend == kPendExit;
-            const uint32_t idx = leaving ? L.entered : (L.pend & 0x1fffffffu);
-            const uint32_t kind = L.pend >> 30;
-            // the whole 112-byte record is fetched at once (both matrices and the tags) so that no second
+        // ---- NODE: one step of the scene-node scan (trace.cu:51-68, 166-193).  A lane whose BVH walk has just ended
+        // first leaves that mesh (world position of its hit, Node::FromLocal for the ray: trace.cu:64-66, 191); then the
+        // box of the next scene node is tested, and if the query has to enter the node it does so in the same turn:
+        // Node::ToLocal, then the sphere / plane test in place or the start of a BVH walk (trace.cu:61-66, 188-191;
+        // objects.cu:7-159).
+        auto op_node = [&]() -> uint32_t {
+            if (L.pend == kPendExit) {
+                const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + L.entered);
+                const float4 r3 = xp[3], r4 = xp[4], r5 = xp[5];
+                const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
+                if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
+                L.trav = false;
+                L.pend = 0;
+                xform_ray(tm, L.pdx, L.pdy, L.pdz);
+                L.qinv = recip3(L.qdir());
+                L.node = by_mask ? first_candidate() : L.entered + 1;
+                if (L.node >= node_count) return query_done();
+            }
+            // node `node` is half A of its record, node + 1 is half B.  Closest hit enters a node whose box is
+            // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
+            // subtree of a node with an object whose box it misses (trace.cu:171-185).
+            // (The half after the last node of an odd list is a dummy without an object and with an empty box.)
+            const float4* rp = reinterpret_cast<const float4*>(pairs + L.node);
+            const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
+            float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
+            float dA, dB;
+            const bool hitA = slab(f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, L.qpos(), L.qinv, L.limit, dA);
+            const bool hitB = slab(f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, L.qpos(), L.qinv, L.limit, dB);
+            if (hitA) tA = dA;
+            if (hitB) tB = dB;
+            const uint32_t kind_a = node_ref_kind(ref_a), kind_b = node_ref_kind(ref_b);
+            const uint32_t after_a = node_ref_after(ref_a), after_b = node_ref_after(ref_b);
+            const bool sh = L.shadow;
+            bool enter_a, enter_b;
+            if (by_mask) {
+                // Scan by candidates: half A is the lowest candidate, half B is looked at when it is one too.  Nodes in
+                // between were certain misses; a candidate object node that a shadow ray misses takes its subtree along.
+                const uint32_t i = L.node;
+                enter_a = hitA & (sh | (tA < L.hz));
+                unsigned long long m = L.mask & ~(1ull << i);
+                if (sh & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << i) - 1ull);
+                const bool cand_b = !enter_a & (i < 63u) & (((m >> ((i + 1u) & 63u)) & 1ull) != 0);
+                enter_b = cand_b & hitB & (sh | (tB < L.hz));
+                if (cand_b) {
+                    m &= ~(2ull << i);
+                    if (sh & !hitB) m &= ~(((1ull << (after_b & 63u)) - 1ull) | (after_b >= 64u ? ~0ull : 0ull)) | ((4ull << i) - 1ull);
+                }
+                L.mask = m;
+                if (!(enter_a | enter_b)) {
+                    L.node = first_candidate();
+                    return after_scan();
+                }
+            } else {
+                const bool obj_a = kind_a != CRT_OBJ_NONE, obj_b = kind_b != CRT_OBJ_NONE;
+                enter_a = obj_a & hitA & (sh | (tA < L.hz));
+                const bool jump_a = sh & obj_a & (after_a != L.node + 1);            // shadow ray past a missed subtree
+                const bool look_b = !(enter_a | jump_a);
+                enter_b = look_b & obj_b & hitB & (sh | (tB < L.hz));
+                if (kCount) {
+                    tally.node_box_tests += (obj_a ? 1u : 0u) + ((look_b & obj_b) ? 1u : 0u);
+                    // every box the full scan finds hit must be a candidate of the mask the plain kernels scan by
+                    if (S.scan_mask) {
+                        const bool chk_a = obj_a & hitA, chk_b = look_b & obj_b & hitB;
+                        tally.scan_checks += (chk_a ? 1u : 0u) + (chk_b ? 1u : 0u);
+                        tally.scan_violations += ((chk_a && !((L.mask >> (L.node & 63u)) & 1ull)) ? 1u : 0u) + ((chk_b && !((L.mask >> ((L.node + 1u) & 63u)) & 1ull)) ? 1u : 0u);
+                    }
+                }
+                if (!(enter_a | enter_b)) {
+                    L.node = jump_a ? after_a : ((sh & obj_b) ? after_b : L.node + 2);
+                    return after_scan();
+                }
+            }
+            const uint32_t idx = enter_a ? L.node : L.node + 1u;
+            const uint32_t kind = enter_a ? kind_a : kind_b;
+            // the whole 112-byte record is fetched at once (both matrices and the tags) so that no further
             // memory round trip follows the object test
             const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
             const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r3 = xp[3], r4 = xp[4], r5 = xp[5], r6 = xp[6];
             const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
             const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
-            if (leaving) {
-                if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
-                L.trav = false;
+            TALLY(node_enters);
+            xform_ray(itm, L.pdx, L.pdy, L.pdz);
+            if (kind == CRT_OBJ_MESH) {
+                L.qinv = recip3(L.qdir());
+                L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
+                return resolve(true, __float_as_uint(r6.x), 0.0f);
+            }
+            const f3 pos = L.qpos(), dir = L.qdir();
+            bool got = false, front = true;
+            float t = 0;
+            if (kind == CRT_OBJ_SPHERE) {
+                TALLY(sphere_tests);
+                if (!(dot(dir, pos) >= 0)) {
+                    const float a = dot(dir, dir);
+                    const float b = dot(dir, pos) * 2;
+                    const float c = dot(pos, pos) - 1;
+                    const float det = b * b - 4 * a * c;
+                    if (!(det < 0)) {
+                        const float sq = sqrtf(det);
+                        const float tf = (-b - sq) / (2 * a);
+                        const float tb = (-b + sq) / (2 * a);
+                        if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
+                        else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
+                        else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
+                    }
+                }
             } else {
-                TALLY(node_enters);
-                xform_ray(itm, L.pdx, L.pdy, L.pdz);
-                if (kind == CRT_OBJ_MESH) {
-                    L.qinv = recip3(L.qdir());
-                    L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
-                    return resolve(true, __float_as_uint(r6.x), 0.0f);
-                }
-                const f3 pos = L.qpos(), dir = L.qdir();
-                bool got = false, front = true;
-                float t = 0;
-                if (kind == CRT_OBJ_SPHERE) {
-                    TALLY(sphere_tests);
-                    if (!(dot(dir, pos) >= 0)) {
-                        const float a = dot(dir, dir);
-                        const float b = dot(dir, pos) * 2;
-                        const float c = dot(pos, pos) - 1;
-                        const float det = b * b - 4 * a * c;
-                        if (!(det < 0)) {
-                            const float sq = sqrtf(det);
-                            const float tf = (-b - sq) / (2 * a);
-                            const float tb = (-b + sq) / (2 * a);
-                            if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
-                            else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
-                            else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
-                        }
-                    }
-                } else {
-                    TALLY(plane_tests);
-                    if (!(dir.z == 0)) {
-                        t = -pos.z / dir.z;
-                        const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
-                        if (in_range && ((dir.z < 0) || (dir.z > 0))) {
-                            const f3 p = pos + t * dir;
-                            if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
-                        }
+                TALLY(plane_tests);
+                if (!(dir.z == 0)) {
+                    t = -pos.z / dir.z;
+                    const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
+                    if (in_range && ((dir.z < 0) || (dir.z > 0))) {
+                        const f3 p = pos + t * dir;
+                        if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
                     }
                 }
-                if (got) {
-                    if (L.shadow) return shadow_blocked();
-                    const f3 p = pos + t * dir;
-                    L.hz = t;
-                    L.hpos = xform_point(tm, p);
-                    L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
-                    L.h_node = idx; L.h_front = front;
-                    L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
-                }
+            }
+            if (got) {
+                if (L.shadow) return shadow_blocked();
+                const f3 p = pos + t * dir;
+                L.hz = t;
+                L.hpos = xform_point(tm, p);
+                L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
+                L.h_node = idx; L.h_front = front;
+                L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
             }
             xform_ray(tm, L.pdx, L.pdy, L.pdz);
             L.qinv = recip3(L.qdir());
@@ -790,7 +807,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            queue_push(&ctl.shade_tail, shade_ring, post, L.slot);
+            queue_push(&ctl.shade_tail[0], shade_ring[0], post && L.pk == PK_CLOSEST_DONE, L.slot);
+            queue_push(&ctl.shade_tail[1], shade_ring[1], post && L.pk != PK_CLOSEST_DONE, L.slot);
             if (post) state = S_IDLE;
             uint32_t slot = 0;
             const bool got = queue_pop(&ctl.ray_head, &ctl.ray_tail, ray_ring, state == S_IDLE, 1u, n_slots, slot, &ctl.abort);
@@ -808,7 +826,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 L.qinv = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
                 L.node = c.w;
                 L.mask = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
-                L.trav = false;
+                L.trav = false; L.pend = 0;
                 L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
                 // no node of the scene can be hit at all: the query is over before its first box step
                 state = after_scan();
@@ -834,10 +852,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             uint32_t best;
             {
                 const uint32_t n_leaf = (uint32_t)__popcll(__ballot(state == S_LEAF));
-                const uint32_t n_xf = (uint32_t)__popcll(__ballot(state == S_XFORM));
+                const uint32_t n_xf = (uint32_t)__popcll(__ballot(state == S_NODE));
                 const uint32_t n_post = (uint32_t)__popcll(__ballot(state == S_POST));
                 const uint32_t n_idle = 64u - n_box - n_leaf - n_xf - n_post;
-                const uint32_t special = n_leaf >= n_xf ? (uint32_t)S_LEAF : (uint32_t)S_XFORM;
+                const uint32_t special = n_leaf >= n_xf ? (uint32_t)S_LEAF : (uint32_t)S_NODE;
                 const uint32_t n_special = n_leaf >= n_xf ? n_leaf : n_xf;
                 // idle lanes count toward an exchange only while the ray queue has something for them
                 uint32_t n_take = 0;
@@ -845,7 +863,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 const uint32_t n_ex = n_post + n_take;
                 if (kCount) {      // census at every vote: lanes without a query, and (once per wave) the fill of the two queues
                     tally.turns[6]++; tally.lanes[6] += state == S_IDLE; tally.lanes[7] += state == S_POST;
-                    if ((tid & 63u) == 0) { tally.cycles[6] += lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head); tally.cycles[7] += lds_ld(&ctl.shade_tail) - lds_ld(&ctl.shade_head); }
+                    if ((tid & 63u) == 0) { tally.cycles[6] += lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head); tally.cycles[7] += (lds_ld(&ctl.shade_tail[0]) - lds_ld(&ctl.shade_head[0])) + (lds_ld(&ctl.shade_tail[1]) - lds_ld(&ctl.shade_head[1])); }
                 }
                 if (n_ex >= S.sched_exchange_min) best = S_POST;
                 else if (n_special >= S.sched_special_min) best = special;
@@ -874,7 +892,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     break;
                 }
                 case S_LEAF: if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); break;
-                case S_XFORM: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_XFORM; } if (state == S_XFORM) state = op_xform(); break;
+                case S_NODE: if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_NODE; } if (state == S_NODE) state = op_node(); break;
                 default:
                     if (kCount) { tally.turns[4]++; tally.lanes[4] += (state == S_POST || state == S_IDLE); }
                     op_exchange();
@@ -882,7 +900,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             }
             if (kCount) {
                 const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
-                switch (best) { case S_BOX: tally.cycles[0] += dt; break; case S_LEAF: tally.cycles[1] += dt; break; case S_XFORM: tally.cycles[2] += dt; break; default: tally.cycles[4] += dt; break; }
+                switch (best) { case S_BOX: tally.cycles[0] += dt; break; case S_LEAF: tally.cycles[1] += dt; break; case S_NODE: tally.cycles[2] += dt; break; default: tally.cycles[4] += dt; break; }
             }
         }
     } else {
@@ -905,7 +923,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             path_sections[wave * 8 + i] += t_n - sect_clock[wave]; sect_clock[wave] = t_n; } } while (0)
 
         // one shading turn for the lane's slot; returns what becomes of the slot
-        auto serve = [&](bool have, uint32_t slot) -> uint32_t {
+        // (kind: std::true_type for slots of the closest-hit queue, std::false_type for the other queue)
+        auto serve = [&](auto kind, bool have, uint32_t slot) -> uint32_t {
+            constexpr bool kClosest = decltype(kind)::value;
             uint32_t result = R_NONE;
             uint32_t* const rec = slot_rec(have ? slot : 0u);
             uint32_t pk = have ? rec[kRecHit] : (uint32_t)PK_NEW_PATH;
@@ -917,7 +937,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
 
             // ---- a slot without a pixel takes the next one of the global queue: consecutive items, one atomic per wave
             {
-                const bool need = have && pk == PK_FETCH;
+                const bool need = !kClosest && have && pk == PK_FETCH;
                 const unsigned long long mask = __ballot(need);
                 if (mask != 0) {
                     if (kCount) { tally.turns[5]++; tally.lanes[5] += need; }
@@ -968,7 +988,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             f3 qpos = mk3(0, 0, 0), qdir = mk3(0, 0, 1), hpos = mk3(0, 0, 0);
             float hz = CRT_BIGFLOAT;
 
-            if (pk == PK_SHADOW_CLEAR || pk == PK_SHADOW_BLOCKED) {
+            if (!kClosest && (pk == PK_SHADOW_CLEAR || pk == PK_SHADOW_BLOCKED)) {
                 // end of TraceShadowRay: add the light sample if nothing was in the way (trace.cu:137-143)
                 const uint4 p4 = path4[4], p5 = path4[5];
                 const uint32_t flags = p4.w;
@@ -976,7 +996,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 alive = (flags & 2u) != 0;
                 next_dir = mk3(__uint_as_float(p4.x), __uint_as_float(p4.y), __uint_as_float(p4.z));
                 hpos = mk3(__uint_as_float(p5.w), __uint_as_float(path4[6].x), __uint_as_float(path4[6].y));
-            } else if (pk == PK_CLOSEST_DONE) {
+            } else if (kClosest) {
                 const uint4* hit4 = reinterpret_cast<const uint4*>(rec + kRecHit);
                 const uint4 h0 = hit4[0], h1 = hit4[1], h2 = hit4[2], h3 = hit4[3];
                 hz = __uint_as_float(h0.y);
@@ -1298,8 +1318,12 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 const uint32_t ready = lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head);
                 if (ready >= S.serve_low_water && patience < S.serve_patience) min_take = S.serve_batch_min;
             }
+            // the fuller of the two shading queues
+            const uint32_t fill0 = lds_ld(&ctl.shade_tail[0]) - lds_ld(&ctl.shade_head[0]);
+            const uint32_t fill1 = lds_ld(&ctl.shade_tail[1]) - lds_ld(&ctl.shade_head[1]);
+            const uint32_t which = fill1 > fill0 ? 1u : 0u;
             uint32_t slot = 0;
-            const bool have = queue_pop(&ctl.shade_head, &ctl.shade_tail, shade_ring, true, min_take, n_slots, slot, &ctl.abort);
+            const bool have = queue_pop(&ctl.shade_head[which], &ctl.shade_tail[which], shade_ring[which], true, min_take, n_slots, slot, &ctl.abort);
             if (__ballot(have) == 0) {
                 patience++;
                 if (!idle_wait()) break;
@@ -1309,10 +1333,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             unsigned long long t_start = 0;
             if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.turns[3]++; tally.lanes[3] += have; }
-            const uint32_t result = serve(have, slot);
+            const uint32_t result = which == 0 ? serve(std::true_type{}, have, slot) : serve(std::false_type{}, have, slot);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             queue_push(&ctl.ray_tail, ray_ring, result == R_RAY, slot);
-            queue_push(&ctl.shade_tail, shade_ring, result == R_REFETCH, slot);
+            queue_push(&ctl.shade_tail[1], shade_ring[1], result == R_REFETCH, slot);
             const unsigned long long retired = __ballot(result == R_RETIRE);
             if (retired != 0 && lane_rank(__ballot(true)) == 0) atomicSub(&ctl.live, (uint32_t)__popcll(retired));
             if (kCount) tally.cycles[3] += __builtin_amdgcn_s_memtime() - t_start;
@@ -1381,7 +1405,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void convert_kernel(const float* __restr
 // Tile order for the next pass: tiles sorted by the cost the pass just finished measured, costliest
 // first, so that the lanes' last pixels are cheap ones and the persistent grid drains evenly.  One
 // block: counting sort over 2048 cost classes (order inside a class is arbitrary).
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, int interleave) {
     __shared__ uint32_t bins[2048];
     __shared__ uint32_t max_cost;
     const uint32_t t = threadIdx.x;
@@ -1400,8 +1424,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
         for (uint32_t b = 0; b < 2048; b++) { const uint32_t c = bins[b]; bins[b] = run; run += c; }
     }
     __syncthreads();
-    for (uint32_t i = t; i < n; i += 1024)
-        order[atomicAdd(&bins[2047u - (uint32_t)((unsigned long long)cost[i] * 2047ull / top)], 1u)] = i;
+    // Costliest first, but with the cheap half of the list interleaved from its cheap end: expensive pixels are
+    // traversal-heavy and cheap ones shading-heavy, and a block's fixed split of traversal and shading waves wants a
+    // steady mix of both; the tiles handed out last are then the middle of the list.
+    for (uint32_t i = t; i < n; i += 1024) {
+        const uint32_t p = atomicAdd(&bins[2047u - (uint32_t)((unsigned long long)cost[i] * 2047ull / top)], 1u);
+        order[interleave && p > (n - 1u) / 2u ? 2u * (n - 1u - p) + 1u : (interleave ? 2u * p : p)] = i;
+    }
 }
 
 // PrepareForDenoise (math/color.cu:32-51): the three accumulators scaled by 1 / passes into the float3
