@@ -22,4 +22,10 @@ run sq3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INST
 run l2 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE || exit 1
 run fetch --kernel-trace --pmc FETCH_SIZE || exit 1
 run write --kernel-trace --pmc WRITE_SIZE || exit 1
-find "$OUT" -name "*.csv" | head -40
+{
+  echo "# rocprofv3 summary of the trace kernel, MI355X; counters are sums over the launches of one pass (count in brackets)"
+  echo "# command: tools/profile_bench.sh $TAG $*  ->  rocprofv3 <pass> -- python3 bench.py $ARGS"
+  echo "# kernel_source_sha1: $(cd "$ROOT" && python3 -c 'import bench; print(bench.kernel_source_digest())' 2>/dev/null)"
+  python3 "$ROOT/tools/summarize_prof.py" "$OUT"
+} > "$ROOT/gpurun_out/prof_${TAG}_summary.txt"
+echo "summary: gpurun_out/prof_${TAG}_summary.txt"

@@ -10,7 +10,7 @@ ctx = crt.Context(0); ctx.upload(s)
 ctx.render_pass(0, spp); ctx.clear()      # first pass measures the tile costs the counted pass is scheduled by
 ctx.render_pass_counted(0, spp)
 print("counted kernel ms", ctx.last_kernel_ms())
-st = ctx.stats(); print(st)
+st = ctx.stats(); print(st); print("scan", ctx.scan_check())
 rays = st["closest_rays"] + st["shadow_rays"]
 tot = 0
 sched = ctx.schedule_stats()
