@@ -462,9 +462,10 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cam_pos, cam.position, 12); S.dof = cam.dof; S.pixel_size = cam.pixel_size;
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
-    // LDS holds at most kLdsStackEntries slots per lane (4 blocks of 256 threads stay resident); deeper trees use the
-    // kernel variant whose stack overflows into the side buffer
-    constexpr uint32_t kLdsStackEntries = 19;
+    // LDS holds at most kLdsStackEntries stack entries per traversal lane (two blocks of 512 threads stay resident);
+    // deeper trees use the kernel variant whose stack overflows into the side buffer.  CRT_STACK_ENTRIES overrides the
+    // number (tests: the same scene with the whole stack in LDS, or with almost all of it in the side buffer).
+    const uint32_t kLdsStackEntries = crt::knob_value(getenv("CRT_STACK_ENTRIES"), 19, 2, 66);
     const uint32_t stack_total = max_depth + 2;
     ctx->deep = stack_total > kLdsStackEntries;
     ctx->stack_overflow = ctx->deep ? stack_total - kLdsStackEntries : 0;
