@@ -177,8 +177,9 @@ struct Loader {
     static mat34 mat_rotation(f3 axis, float degrees) {
         mat34 m = mat_identity();
         const float rad = kDeg2Rad * degrees;
-        const float sina = crtm::det_sinf(rad);
-        const float cosa = crtm::det_cosf(rad);
+        // host code in the reference: the C library's sinf / cosf, not the pinned device replacements
+        const float sina = sinf(rad);
+        const float cosa = cosf(rad);
         const float t = 1.0f - cosa;
         const f3 a = t * axis;
         const float txy = a.x * axis.y, txz = a.x * axis.z, tyz = a.y * axis.z;
@@ -410,7 +411,7 @@ void camera_derive(crt_camera& cam) {
     const f3 cZ = normalized(target - pos);
     const f3 cX = cross_literal(cZ, normalized(up));
     const f3 cY = cross_literal(cX, cZ);
-    const float plane_h = 2 * focal * crtm::det_tanf(fov_rad * 0.5f);
+    const float plane_h = 2 * focal * tanf(fov_rad * 0.5f);      // host code in the reference: the C library's tanf
     const float plane_w = plane_h * aspect;
     cam.pixel_size = plane_h / (float)cam.height;
     const f3 centre = pos + focal * cZ;

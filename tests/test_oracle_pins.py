@@ -21,6 +21,20 @@ def test_center_hit_counts_match_the_reference(name):
     assert o.count_center_hits() == ANCHORS["center_hits_1280x720"][name]
 
 
+@pytest.mark.parametrize("name", sorted(ANCHORS["rays_1spp_pass0_1280x720"]))
+def test_ray_counts_match_the_reference(name):
+    """The number of closest-hit and shadow queries of a whole pass depends on everything a path touches: geometry,
+    materials, textures, lights, the random sequence and Russian roulette.  The glibc flavour of the oracle (what a
+    host build of the reference computes) reproduces the counts recorded from the reference exactly."""
+    want = ANCHORS["rays_1spp_pass0_1280x720"][name]
+    o = orc.OracleScene(scene_path(name), "glibc")
+    assert (o.width, o.height) == (1280, 720)
+    _, cnt = o.render(0, 1, count=True, threads=os.cpu_count() or 1)
+    assert cnt["closest_rays"] == want["closest"]
+    if "shadow" in want:
+        assert cnt["shadow_rays"] == want["shadow"]
+
+
 def test_bvh_sizes_match_the_reference():
     want = ANCHORS["bvh_nodes"]
     got = {
