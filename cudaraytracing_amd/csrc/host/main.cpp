@@ -1,39 +1,61 @@
 // crt_render: command-line front end.  Replaces main.cu:8-21 (hard-coded scene +
 // viewport) and, with --sequence, Sequence::DoRender (renderer/sequence.h:63-99).
 #include <dirent.h>
+#include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 #include "renderer.h"
 
 static void usage() {
     printf("usage: crt_render <scene.xml|scene.crtscene> [-o out.png] [--spp N] [--passes N] [--width W --height H]\n"
            "                  [--assets DIR] [--device N]\n"
-           "       crt_render --sequence <dir> [--out-dir DIR] [same options]\n"
+           "       crt_render --sequence <dir> [--out-dir DIR] [--devices N] [--workers-per-device K] [same options]\n"
+           "           every *.xml (or *.crtscene) of <dir>, one frame per worker: frames are handed out from a queue to\n"
+           "           N x K workers, worker w renders on device w %% N (K > 1 overlaps one frame's scene load and BVH\n"
+           "           build with another frame's kernels on the same GPU)\n"
            "       crt_render --bake <scene.xml> <out.crtscene> [--assets DIR] [--width W --height H]\n");
 }
 
-static bool render_one(const crt::RenderSettings& st, const std::string& scene, const std::string& out) {
-    crt::Renderer r(st);
-    if (!r.LoadScene(scene.c_str())) return false;
+static std::mutex g_print;
+
+// One frame from scratch, as Sequence::DoRender does it (renderer/sequence.h:79-88): load, render every pass, save;
+// the report line carries the frame's load, render and save times.
+static bool render_one(crt::Renderer& r, const crt::RenderSettings& st, const std::string& scene, const std::string& out) {
     const auto t0 = std::chrono::steady_clock::now();
+    if (!r.LoadScene(scene.c_str())) return false;
+    const auto t1 = std::chrono::steady_clock::now();
     r.BeginRendering(true);
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (!r.GetImage().SaveImage(out.c_str())) { printf("ERROR: cannot write %s\n", out.c_str()); return false; }
-    printf("%s -> %s: %ux%u, %d x %d spp, frame %.2f ms (kernels %.2f ms), %.1f Mrays/s\n", scene.c_str(), out.c_str(),
-           r.GetImage().width, r.GetImage().height, st.passes, st.samples, ms, r.LastRenderKernelMs(),
+    const auto t2 = std::chrono::steady_clock::now();
+    const bool saved = r.GetImage().SaveImage(out.c_str());
+    const auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::lock_guard<std::mutex> guard(g_print);
+    if (!saved) { printf("ERROR: cannot write %s\n", out.c_str()); return false; }
+    printf("%s -> %s: %ux%u, %d x %d spp, device %d, load %.1f ms, render %.2f ms (kernels %.2f ms), save %.1f ms, %.1f Mrays/s\n", scene.c_str(), out.c_str(),
+           r.GetImage().width, r.GetImage().height, st.passes, st.samples, st.device, ms(t0, t1), ms(t1, t2), r.LastRenderKernelMs(), ms(t2, t3),
            r.LastRenderKernelMs() > 0 ? (double)r.LastRenderRays() / r.LastRenderKernelMs() * 1e-3 : 0.0);
+    fflush(stdout);
     return true;
+}
+
+static bool has_suffix(const std::string& n, const char* suffix) {
+    const size_t k = strlen(suffix);
+    return n.size() > k && n.compare(n.size() - k, k, suffix) == 0;
 }
 
 int main(int argc, char** argv) {
     crt::RenderSettings st;
     st.samples = 64; st.passes = 1;
     std::string scene, out = "output.png", seq_dir, out_dir = "output", bake_in, bake_out;
+    int devices = 1, workers_per_device = 1;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -46,6 +68,8 @@ int main(int argc, char** argv) {
         else if (a == "--device") st.device = atoi(val());
         else if (a == "--sequence") seq_dir = val();
         else if (a == "--out-dir") out_dir = val();
+        else if (a == "--devices") devices = std::max(1, atoi(val()));
+        else if (a == "--workers-per-device") workers_per_device = std::max(1, atoi(val()));
         else if (a == "--bake") { bake_in = val(); bake_out = val(); }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else scene = a;
@@ -63,19 +87,40 @@ int main(int argc, char** argv) {
         if (DIR* d = opendir(seq_dir.c_str())) {
             while (dirent* e = readdir(d)) {
                 const std::string n = e->d_name;
-                if (n.size() > 4 && n.substr(n.size() - 4) == ".xml") files.push_back(n);
+                if (has_suffix(n, ".xml") || has_suffix(n, ".crtscene")) files.push_back(n);
             }
             closedir(d);
+        } else {
+            printf("ERROR: cannot read directory %s\n", seq_dir.c_str());
+            return 1;
         }
         std::sort(files.begin(), files.end());
+        mkdir(out_dir.c_str(), 0777);      // (an existing directory is fine)
+        // Frames are independent: a queue of frames, one worker per (device, slot); each worker keeps one renderer
+        // (one device context) and renders whole frames from scratch.
         const auto t0 = std::chrono::steady_clock::now();
-        int failed = 0;
-        for (const std::string& f : files)
-            if (!render_one(st, seq_dir + "/" + f, out_dir + "/" + f.substr(0, f.size() - 4) + ".png")) failed++;
-        printf("Total render time is %.3f s for %zu frames (%d failed).\n",
-               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), files.size(), failed);
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed{0};
+        const int workers = devices * workers_per_device;
+        std::vector<std::thread> pool;
+        for (int w = 0; w < workers; w++)
+            pool.emplace_back([&, w]() {
+                crt::RenderSettings mine = st;
+                mine.device = st.device + w % devices;
+                crt::Renderer r(mine);
+                for (size_t i = next++; i < files.size(); i = next++) {
+                    const std::string& f = files[i];
+                    const std::string stem = f.substr(0, f.rfind('.'));
+                    if (!render_one(r, mine, seq_dir + "/" + f, out_dir + "/" + stem + ".png")) failed++;
+                }
+            });
+        for (auto& t : pool) t.join();
+        const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("Total render time is %.3f s for %zu frames on %d device(s) x %d worker(s): %.2f frames/s (%d failed).\n",
+               total, files.size(), devices, workers_per_device, total > 0 ? files.size() / total : 0.0, failed.load());
         return failed ? 1 : 0;
     }
     if (scene.empty()) { usage(); return 2; }
-    return render_one(st, scene, out) ? 0 : 1;
+    crt::Renderer r(st);
+    return render_one(r, st, scene, out) ? 0 : 1;
 }
