@@ -1,138 +1,179 @@
-// Wavefront OBJ reader with the reference loader's behaviour
-// (Mesh::LoadFromFileObj, scene/mesh.cu:14-200): commands v / vt / vn / f only,
-// whitespace runs collapse to one blank, '#' lines are skipped, polygons are
-// fan-triangulated, negative indices count from the end of the list read so
-// far, and index triples for vt / vn are recorded for a face only once a vt /
-// vn record or index has been seen.
+// Wavefront OBJ reader.  Reads what Mesh::LoadFromFileObj reads (scene/mesh.cu:14-200) and arrives at the same
+// arrays: records v / vt / vn / f only, everything else ignored; '#' starts a comment line; blanks of any kind and
+// number separate fields; polygons become triangle fans around their first corner; a negative index counts back
+// from the end of the list as read so far; a face gets a texture / normal index triple only once the file has
+// shown a vt / vn record or a corner with that field.
+//
+// One quirk of the reference decides real data: it holds a line in 1024 bytes, so a record whose text (blank runs
+// counted as one character) exceeds 1023 characters is cut there, the cut may fall inside a number, and the rest of
+// the line is read as a record of its own, which no keyword matches.  models/final/body_cell_018.obj has such a
+// polygon, so the cut is reproduced (next_record).
+//
+// The file is held in memory; next_record yields one record at a time with its blank runs already reduced, a token
+// cursor walks it, and numbers go through strtof.  Deliberate differences, none of which a shipped model meets: a
+// record's missing components are 0 (the reference leaves them unset, mesh.cu:54) and every index is range-checked
+// at the end because the GPU reads the arrays unchecked.
 #include "host.h"
 
-#include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace crt {
 
 namespace {
 
-struct LineReader {
-    const std::vector<uint8_t>& d;
-    size_t pos = 0;
-    bool eof = false;            // set once a read went past the end (feof semantics)
-    char line[1100];
-    explicit LineReader(const std::vector<uint8_t>& data) : d(data) {}
+constexpr size_t kRecordLimit = 1023;     // characters of one record (the reference's line buffer less its terminator)
 
-    int get() {
-        if (pos < d.size()) return d[pos++];
-        eof = true;
-        return -1;
-    }
+// End of a line: newline, carriage return, NUL or the end of the buffer.
+inline bool ends_line(const char* p, const char* end) { return p == end || *p == '\n' || *p == '\r' || *p == '\0'; }
+inline bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\v' || c == '\f'; }
 
-    // Returns the length of the next non-empty, non-comment line (0 at end of file).
-    int read_line() {
-        int c = get();
-        while (!eof) {
-            while (c >= 0 && isspace(c)) c = get();
-            if (c == '#') { while (!eof && c != '\n' && c != '\r' && c != '\0') c = get(); }
-            else break;
-        }
-        int i = 0;
-        bool inspace = false;
-        while (i < 1024 - 1) {
-            if (eof || c == '\n' || c == '\r' || c == '\0') break;
-            if (isspace(c)) inspace = true;
-            else {
-                if (inspace) line[i++] = ' ';
-                inspace = false;
-                line[i++] = (char)c;
-            }
-            c = get();
-        }
-        line[i] = '\0';
-        return i;
+// The next record of the file into `rec`: leading white space, empty lines and '#' lines are passed over, every run of
+// blanks inside the record becomes one space and trailing blanks vanish.  A record stops at the end of its line or at
+// kRecordLimit characters, whichever comes first; in the second case the character after the cut is lost (the
+// reference has already taken it from the stream) and the remainder of the line comes back as the next record.
+// False once the file has nothing more (a NUL byte also ends the file, as an empty record does in the reference).
+bool next_record(const char*& p, const char* end, std::string& rec) {
+    for (;;) {
+        while (p < end && (is_blank(*p) || *p == '\n' || *p == '\r')) p++;
+        if (p < end && *p == '#') { while (!ends_line(p, end)) p++; }
+        else break;
     }
+    rec.clear();
+    bool gap = false;
+    while (rec.size() < kRecordLimit) {
+        if (ends_line(p, end)) { if (p < end) p++; return !rec.empty(); }
+        const char c = *p++;
+        if (is_blank(c)) { gap = true; continue; }
+        if (gap) rec.push_back(' ');
+        gap = false;
+        rec.push_back(c);
+    }
+    if (p < end) p++;
+    return true;
+}
 
-    bool is_command(const char* cmd) const {
-        int i = 0;
-        while (cmd[i] != '\0') { if (cmd[i] != line[i]) return false; i++; }
-        return line[i] == '\0' || line[i] == ' ';
-    }
+// The next blank-separated token of the line at *cursor; false when the line has no more.
+bool next_token(const char*& cursor, const char* end, const char*& tok, size_t& len) {
+    while (!ends_line(cursor, end) && is_blank(*cursor)) cursor++;
+    if (ends_line(cursor, end)) return false;
+    tok = cursor;
+    while (!ends_line(cursor, end) && !is_blank(*cursor)) cursor++;
+    len = (size_t)(cursor - tok);
+    return true;
+}
 
-    // Components the line does not supply are zero (the reference leaves them
-    // uninitialised, mesh.cu:54; only the unused third texture coordinate is affected
-    // in the shipped models).
-    void read_float3(float out[3]) const {
-        out[0] = out[1] = out[2] = 0.0f;
-        if (strlen(line) >= 2) sscanf(line + 2, "%f %f %f", &out[0], &out[1], &out[2]);
+// Up to three numbers after the record's keyword; parsing stops at the first token that is not a number.
+void read_triple(const char*& cursor, const char* end, float out[3]) {
+    out[0] = out[1] = out[2] = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        const char* tok; size_t len;
+        if (!next_token(cursor, end, tok, len)) return;
+        char text[64];
+        if (len >= sizeof text) return;
+        memcpy(text, tok, len); text[len] = '\0';
+        char* stop = nullptr;
+        const float v = strtof(text, &stop);
+        if (stop == text) return;
+        out[k] = v;
     }
+}
+
+// One corner of a face, "v", "v/vt", "v//vn" or "v/vt/vn".  A field counts as present once it has a digit; its value is
+// the decimal number made of the field's digits (other characters are skipped), one-based, or counted back from
+// `counts[field]` when a '-' has appeared anywhere earlier in the corner (the sign carries over to later fields).
+struct Corner {
+    bool present[3] = {false, false, false};
+    uint32_t index[3] = {0, 0, 0};
 };
+
+Corner parse_corner(const char* tok, size_t len, const uint32_t counts[3]) {
+    Corner c;
+    int field = 0;
+    bool from_end = false;
+    uint32_t number = 0;
+    for (size_t i = 0; i < len; i++) {
+        const char ch = tok[i];
+        if (ch == '/') { field++; number = 0; }
+        else if (ch == '-') from_end = true;
+        else if (ch >= '0' && ch <= '9') {
+            number = number * 10u + (uint32_t)(ch - '0');
+            if (field < 3) {
+                c.present[field] = true;
+                c.index[field] = from_end ? counts[field] - number : number - 1u;      // (unsigned wrap on 0: caught by the range check)
+            }
+        }
+    }
+    return c;
+}
 
 }  // namespace
 
 bool obj_load(const char* path, HostMesh& mesh, std::string& err) {
-    FILE* fp = fopen(path, "rb");
-    if (!fp) { err = std::string("cannot open ") + path; return false; }
-    std::vector<uint8_t> data;
-    uint8_t buf[65536];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, fp)) > 0) data.insert(data.end(), buf, buf + n);
-    fclose(fp);
-
+    std::vector<char> text;
+    {
+        FILE* fp = fopen(path, "rb");
+        if (!fp) { err = std::string("cannot open ") + path; return false; }
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, fp)) > 0) text.insert(text.end(), chunk, chunk + got);
+        fclose(fp);
+    }
     mesh = HostMesh();
     mesh.name = path;
-    bool has_normals = false, has_tex = false;
-    LineReader rd(data);
-    while (int rb = rd.read_line()) {
-        if (rd.is_command("v")) {
-            float p[3]; rd.read_float3(p);
-            mesh.v.insert(mesh.v.end(), p, p + 3);
-        } else if (rd.is_command("vt")) {
-            float p[3]; rd.read_float3(p);
-            mesh.vt.insert(mesh.vt.end(), p, p + 3);
-            has_tex = true;
-        } else if (rd.is_command("vn")) {
-            float p[3]; rd.read_float3(p);
-            mesh.vn.insert(mesh.vn.end(), p, p + 3);
-            has_normals = true;
-        } else if (rd.is_command("f")) {
-            int facevert = -1;
-            bool inspace = true, negative = false;
-            int type = 0;
-            unsigned index = 0;
-            uint32_t face[3] = {0, 0, 0}, tface[3] = {0, 0, 0}, nface[3] = {0, 0, 0};
-            auto push = [&]() {
-                mesh.f.insert(mesh.f.end(), face, face + 3);
-                if (has_tex) mesh.ft.insert(mesh.ft.end(), tface, tface + 3);
-                if (has_normals) mesh.fn.insert(mesh.fn.end(), nface, nface + 3);
-            };
-            for (int i = 2; i < rb; i++) {
-                const char ch = rd.line[i];
-                if (ch == ' ') { inspace = true; continue; }
-                if (inspace) {
-                    inspace = false; negative = false; type = 0; index = 0;
-                    if (facevert < 2) {
-                        facevert++;
-                    } else {
-                        // fourth and later corner: emit the previous triangle, keep corner 0 and
-                        // slide the last corner into slot 1 (fan triangulation)
-                        push();
-                        face[1] = face[2]; tface[1] = tface[2]; nface[1] = nface[2];
+
+    // whether faces carry texture / normal index triples yet
+    bool with_tex = false, with_normals = false;
+    const char* file_cursor = text.data();
+    const char* const file_end = text.data() + text.size();
+    std::string record;
+    while (next_record(file_cursor, file_end, record)) {
+        const char* cursor = record.data();
+        const char* const end = record.data() + record.size();
+        const char* key; size_t key_len;
+        if (next_token(cursor, end, key, key_len)) {
+            const bool is_v = key_len == 1 && key[0] == 'v';
+            const bool is_vt = key_len == 2 && key[0] == 'v' && key[1] == 't';
+            const bool is_vn = key_len == 2 && key[0] == 'v' && key[1] == 'n';
+            const bool is_f = key_len == 1 && key[0] == 'f';
+            if (is_v || is_vt || is_vn) {
+                float p[3];
+                read_triple(cursor, end, p);
+                std::vector<float>& list = is_v ? mesh.v : (is_vt ? mesh.vt : mesh.vn);
+                list.insert(list.end(), p, p + 3);
+                with_tex = with_tex || is_vt;
+                with_normals = with_normals || is_vn;
+            } else if (is_f) {
+                // tri[field][slot]: the triangle being assembled, per index kind (0 vertex, 1 texture, 2 normal)
+                uint32_t tri[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                auto emit = [&]() {
+                    mesh.f.insert(mesh.f.end(), tri[0], tri[0] + 3);
+                    if (with_tex) mesh.ft.insert(mesh.ft.end(), tri[1], tri[1] + 3);
+                    if (with_normals) mesh.fn.insert(mesh.fn.end(), tri[2], tri[2] + 3);
+                };
+                const uint32_t counts[3] = {mesh.nv(), mesh.nvt(), mesh.nvn()};
+                int corners = 0;
+                const char* tok; size_t len;
+                while (next_token(cursor, end, tok, len)) {
+                    int slot = corners;
+                    if (corners >= 3) {
+                        // a further corner of a polygon: the triangle so far is done; the fan keeps corner 0 and the
+                        // last corner becomes the middle one
+                        emit();
+                        for (auto& kind : tri) kind[1] = kind[2];
+                        slot = 2;
                     }
+                    corners++;
+                    const Corner c = parse_corner(tok, len, counts);
+                    for (int kind = 0; kind < 3; kind++)
+                        if (c.present[kind]) tri[kind][slot] = c.index[kind];      // (an absent field keeps what the slot held)
+                    with_tex = with_tex || c.present[1];
+                    with_normals = with_normals || c.present[2];
                 }
-                if (ch == '/') { type++; index = 0; }
-                if (ch == '-') negative = true;
-                if (ch >= '0' && ch <= '9') {
-                    index = index * 10 + (unsigned)(ch - '0');
-                    switch (type) {
-                        case 0: face[facevert] = negative ? mesh.nv() - index : index - 1; break;
-                        case 1: tface[facevert] = negative ? mesh.nvt() - index : index - 1; has_tex = true; break;
-                        case 2: nface[facevert] = negative ? mesh.nvn() - index : index - 1; has_normals = true; break;
-                        default: break;
-                    }
-                }
+                emit();
             }
-            push();
         }
-        if (rd.eof) break;
     }
 
     // every index must address its list; the GPU reads them unchecked

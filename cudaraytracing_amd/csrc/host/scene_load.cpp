@@ -239,24 +239,29 @@ struct Loader {
             sc.nodes[my].material_id = it->second;
         }
 
-        mat34 translation = mat_identity(), rotation = mat_identity(), scale = mat_identity();
+        // Local transform: the node's last <translate>, last <rotate> and last <scale> element, always composed as
+        // parent x T x R x S whatever their order in the file (lib/xmlload.cu:274-294).
+        enum { kTranslate, kRotate, kScale };
+        mat34 part[3] = {mat_identity(), mat_identity(), mat_identity()};
         for (const auto& c : e.children) {
-            if (ieq(c->tag, "scale")) {
-                f3 s; read_float3(c.get(), s, mk3(1, 1, 1));
-                scale = mat_identity(); scale.c[0] = s.x; scale.c[4] = s.y; scale.c[8] = s.z;
+            f3 value;
+            if (ieq(c->tag, "translate")) {
+                read_float3(c.get(), value);
+                part[kTranslate] = mat_identity();
+                part[kTranslate].c[9] = value.x; part[kTranslate].c[10] = value.y; part[kTranslate].c[11] = value.z;
             } else if (ieq(c->tag, "rotate")) {
-                f3 s; read_float3(c.get(), s);
-                float a = 0.0f; c->float_attr("angle", a);
-                rotation = mat_rotation(normalized(s), a);
-            } else if (ieq(c->tag, "translate")) {
-                f3 t; read_float3(c.get(), t);
-                translation = mat_identity(); translation.c[9] = t.x; translation.c[10] = t.y; translation.c[11] = t.z;
+                read_float3(c.get(), value);                      // the axis
+                float degrees = 0.0f;
+                c->float_attr("angle", degrees);
+                part[kRotate] = mat_rotation(normalized(value), degrees);
+            } else if (ieq(c->tag, "scale")) {
+                read_float3(c.get(), value, mk3(1, 1, 1));
+                part[kScale] = mat_identity();
+                part[kScale].c[0] = value.x; part[kScale].c[4] = value.y; part[kScale].c[8] = value.z;
             }
         }
-        mat34 pt, ptr, tm;
-        mat_mul(parent, translation, pt);
-        mat_mul(pt, rotation, ptr);
-        mat_mul(ptr, scale, tm);
+        mat34 tm = parent;
+        for (const mat34& m : part) { mat34 product; mat_mul(tm, m, product); tm = product; }
         const mat34 itm = mat_inverse(tm);
         memcpy(sc.nodes[my].tm, tm.c, sizeof tm.c);
         memcpy(sc.nodes[my].itm, itm.c, sizeof itm.c);
@@ -426,13 +431,13 @@ void camera_derive(crt_camera& cam) {
 bool scene_load_xml(const char* xml_path, const char* asset_root, HostScene& scene, std::string& err) {
     std::string perr;
     auto doc = xml_parse_file(xml_path, perr);
-    if (!doc) { err = std::string("failed to load \"") + xml_path + "\": " + perr; return false; }
+    if (!doc) { err = std::string("cannot read ") + xml_path + ": " + perr; return false; }
     const XmlElement* xml = doc->child("xml");
-    if (!xml) { err = "no \"xml\" tag found"; return false; }
+    if (!xml) { err = std::string(xml_path) + ": the document has no <xml> root element"; return false; }
     const XmlElement* xscene = xml->child("scene");
-    if (!xscene) { err = "no \"scene\" tag found"; return false; }
+    if (!xscene) { err = std::string(xml_path) + ": <xml> holds no <scene> element"; return false; }
     const XmlElement* xcam = xml->child("camera");
-    if (!xcam) { err = "no \"camera\" tag found"; return false; }
+    if (!xcam) { err = std::string(xml_path) + ": <xml> holds no <camera> element"; return false; }
     scene = HostScene();
     Loader ld{scene, asset_root, err, {}, {}};
     if (!ld.load_scene(*xscene)) return false;
