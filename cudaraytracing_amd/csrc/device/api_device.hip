@@ -516,7 +516,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.sched_box_min = crt::knob_value(getenv("CRT_SCHED_BOX_MIN"), 20, 1, 64);
     S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
     S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), 8, 1, 64);
-    S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 3 / 4, 1, CRT_BLOCK / 64 - 1);
+    S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
     S.slots = crt::knob_value(getenv("CRT_SLOTS"), 2 * S.trav_waves * 64 < kQueueSize ? 2 * S.trav_waves * 64 : kQueueSize, 64, kQueueSize);
     S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
     S.serve_low_water = crt::knob_value(getenv("CRT_SERVE_LOW_WATER"), 64, 0, kQueueSize);

@@ -38,7 +38,7 @@
 namespace crt {
 
 #ifndef CRT_BLOCK
-#define CRT_BLOCK 512                // threads of a trace-kernel block (the element-wise kernels use it too)
+#define CRT_BLOCK 1024               // threads of a trace-kernel block: one block per CU, so that all traversal and shading waves of a CU share one pool of pixel slots (the element-wise kernels use it too)
 #endif
 #ifndef CRT_WAVES_PER_SIMD
 #define CRT_WAVES_PER_SIMD 4        // register budget 128: the best measured balance of occupancy and spills

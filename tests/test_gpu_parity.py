@@ -277,11 +277,16 @@ def test_ten_million_triangle_scene_at_full_size(gpu_ctx, monkeypatch):
             monkeypatch.delenv("CRT_STACK_ENTRIES", raising=False)
         else:
             monkeypatch.setenv("CRT_STACK_ENTRIES", entries)
+        # the whole 31-entry stack of every lane fits LDS only with fewer traversal waves in the block
+        if entries == "64":
+            monkeypatch.setenv("CRT_TRAV_WAVES", "6")
         gpu_ctx.upload(syn)
         gpu_ctx.clear()
         gpu_ctx.render_pass(0, 1)
         results.append((gpu_ctx.read_accumulators(), gpu_ctx.stats()))
     monkeypatch.delenv("CRT_STACK_ENTRIES", raising=False)
+    monkeypatch.delenv("CRT_TRAV_WAVES", raising=False)
+    gpu_ctx.upload(syn)
     (acc, st) = results[0]
     for other, st_other in results[1:]:
         assert st_other == st
@@ -292,7 +297,10 @@ def test_ten_million_triangle_scene_at_full_size(gpu_ctx, monkeypatch):
     assert np.isfinite(acc[0]).all() and (acc[0] >= 0).all()
     # the teapots cover a good part of the frame: normals were accumulated for hits, misses add the view direction
     assert (np.abs(acc[1]).sum(axis=2) > 0).mean() > 0.99
-    # determinism, and a second pass accumulates on top of the first (renderer.cu:39-61)
+    # determinism (the scene was uploaded afresh with the default block shape), and a second pass accumulates on top
+    # of the first (renderer.cu:39-61)
+    gpu_ctx.render_pass(0, 1)
+    assert same(gpu_ctx.read_accumulators()[0], acc[0])
     gpu_ctx.render_pass(1, 1)
     two = gpu_ctx.read_accumulators()[0]
     assert (two >= acc[0]).all() and (two > acc[0]).any()
