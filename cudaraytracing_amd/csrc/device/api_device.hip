@@ -517,7 +517,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
     S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), 8, 1, 64);
     S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
-    S.slots = crt::knob_value(getenv("CRT_SLOTS"), 2 * S.trav_waves * 64 < kQueueSize ? 2 * S.trav_waves * 64 : kQueueSize, 64, kQueueSize);
+    S.slots = crt::knob_value(getenv("CRT_SLOTS"), 96 * S.trav_waves < kQueueSize ? 96 * S.trav_waves : kQueueSize, 64, kQueueSize);
     S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
     S.serve_low_water = crt::knob_value(getenv("CRT_SERVE_LOW_WATER"), 64, 0, kQueueSize);
     S.serve_patience = crt::knob_value(getenv("CRT_SERVE_PATIENCE"), 64, 0, 1u << 20);

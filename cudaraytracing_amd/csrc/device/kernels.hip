@@ -401,7 +401,7 @@ struct Lane {
 // lanes full while any one pixel still sees its operations in the reference's order.  Both queues are rings of
 // slot numbers in LDS; an entry carries the lap number of its position, so a consumer that has claimed a position
 // knows when the producer's write has landed without a second counter.
-constexpr uint32_t kQueueLog = 10, kQueueSize = 1u << kQueueLog;      // ring positions; slots per block <= kQueueSize
+constexpr uint32_t kQueueLog = 11, kQueueSize = 1u << kQueueLog;      // ring positions; slots per block <= kQueueSize
 constexpr uint32_t kSlotWords = 64;
 constexpr uint32_t kRecRay = 0, kRecHit = 16, kRecPath = 32;
 constexpr uint32_t kMaxWaves = 16;
