@@ -1,28 +1,35 @@
 // gfx950 kernels of the per-pixel trace path.
 //
 // trace_kernel replaces TracePrimaryRays (renderer/trace.cu:7-41) and every
-// device function it reaches.  It is a persistent kernel: each lane owns one
-// pixel at a time, runs that pixel's samples one after another (they share one
-// random stream, renderer/trace.cu:22-25) and, when the pixel is finished,
-// takes the next unowned pixel from a global queue with one wave-aggregated
-// atomic (ballot + mbcnt prefix), so lanes do not idle on short pixels.
+// device function it reaches.  It is a persistent kernel, one 1024-thread block
+// per CU.  A block owns a pool of pixel slots: a slot holds one pixel at a time
+// and runs that pixel's samples one after another (they share one random stream,
+// renderer/trace.cu:22-25); a finished slot takes the next pixel of a global
+// queue with one wave-aggregated atomic (ballot + mbcnt prefix).
 //
-// The work of a pixel is cut into four operations - BOX: slab-test one 64-byte
-// box-pair record (scene-node scan and BVH descent are the same operation);
-// LEAF: test up to two triangles of a leaf; XFORM: enter a scene node or leave a mesh; PATH:
-// everything between two ray queries (shading, light and BSDF sampling, a new
-// camera ray; a lane whose pixel is finished first takes the next one from the
-// queue, in the same turn) - and every lane carries the
-// operation it needs next.  Each turn of the main loop the wave votes (ballot +
-// popcount) and executes one operation for the lanes that wait for it, so a
-// lane in a rare phase does not make the other 63 walk through its code;
-// closest-hit and shadow queries share BOX, LEAF and XFORM.  The order of
-// operations of any one pixel is exactly the reference's, only their
-// interleaving across lanes is scheduled.  Registers hold the traversal state
-// only; what a pixel needs just between two queries (random stream, throughput,
-// pending light sample, ...) lives in a field-major side buffer in global
-// memory.  The per-lane traversal stack lives in LDS, laid out [entry][thread]
-// so that any mix of stack depths is bank-conflict free.
+// Slots, not lanes, own pixels.  Everything a pixel carries from one ray query
+// to the next lives in the slot's 256-byte record in global memory, and two
+// kinds of wave pass slots to each other through rings in LDS (positions
+// reserved with one atomic per wave, entries compacted with ballot + mbcnt):
+//   * traversal waves run ray queries.  A lane takes a ready query of whatever
+//     pixel, walks it, writes the result into the slot and queues the slot for
+//     shading.  The work of a query is cut into three operations - BOX: slab-test
+//     the two children of a BVH node (one 64-byte record); LEAF: up to two
+//     triangles of a leaf; NODE: one step of the scene-node scan (leave the mesh
+//     just walked, test the next node's box, enter it: transform, sphere / plane
+//     test or BVH root) - and each turn the wave votes (ballot + popcount) and
+//     runs one operation for the lanes that wait for it; closest-hit and shadow
+//     queries share all three.  The traversal stack lives in LDS, laid out
+//     [entry][thread] so that any mix of stack depths is bank-conflict free.
+//   * shading waves run everything between two queries of a pixel (hit
+//     attributes, textures, light and BSDF sampling, Russian roulette, the camera
+//     ray of a new path, the next pixel of a finished slot) for up to 64 slots
+//     at a time, whichever lanes finished them, in turns that are all of one
+//     kind (closest-hit query ended / shadow query ended or pixel needed).
+// So both kinds of wave work with their lanes full of the same kind of work,
+// traversal state is the only thing in a traversal lane's registers, and the
+// kernel spills nothing.  The order of operations of any one pixel is exactly
+// the reference's; only their interleaving across pixels is scheduled.
 //
 // Arithmetic keeps the reference's operation order (see crt_vec.h); the file is
 // compiled with -ffp-contract=off and uses the pinned transcendentals of
