@@ -274,15 +274,26 @@ uint32_t trace_grid(const crt_ctx* ctx, int per_cu) {
     return grid > need ? need : grid;
 }
 
+// The build of the trace kernel for this scene: counting or plain, primary hits only or whole paths, deep tree (stack
+// overflow in the side buffer) or not, and one or two words of candidate mask.
+using TraceKernel = void (*)(DevScene, DevPartition, int, const uint32_t*, uint32_t*, DevStats*, int32_t*, int32_t*, float*, uint32_t*);
+
 template <bool kCount, bool kPrimary>
-void launch_trace(crt_ctx* ctx, uint32_t grid, hipStream_t stream, const DevPartition& P, int samples, const uint32_t* jump,
-                  int32_t* out_node, int32_t* out_face, float* out_t) {
-    if (ctx->deep)
-        hipLaunchKernelGGL((trace_kernel<kCount, kPrimary, true>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
-                           ctx->queue, ctx->stats, out_node, out_face, out_t, ctx->cold);
-    else
-        hipLaunchKernelGGL((trace_kernel<kCount, kPrimary, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
-                           ctx->queue, ctx->stats, out_node, out_face, out_t, ctx->cold);
+TraceKernel trace_variant(bool deep, bool wide) {
+    if (deep) return wide ? trace_kernel<kCount, kPrimary, true, true> : trace_kernel<kCount, kPrimary, true, false>;
+    return wide ? trace_kernel<kCount, kPrimary, false, true> : trace_kernel<kCount, kPrimary, false, false>;
+}
+
+TraceKernel trace_variant(const crt_ctx* ctx, bool counted, bool primary) {
+    const bool wide = ctx->S.node_count > 64;
+    if (primary) return trace_variant<false, true>(ctx->deep, wide);
+    return counted ? trace_variant<true, false>(ctx->deep, wide) : trace_variant<false, false>(ctx->deep, wide);
+}
+
+void launch_trace(crt_ctx* ctx, bool counted, bool primary, uint32_t grid, hipStream_t stream, const DevPartition& P, int samples, const uint32_t* jump,
+                  uint32_t* queue, int32_t* out_node, int32_t* out_face, float* out_t, uint32_t* slot_mem) {
+    hipLaunchKernelGGL(trace_variant(ctx, counted, primary), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
+                       queue, ctx->stats, out_node, out_face, out_t, slot_mem);
 }
 
 }  // namespace
@@ -504,7 +515,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
             abs_ += nrt + 9.0 * u * (nat + nt);
         }
         rel *= 1.05; abs_ *= 1.05;
-        const bool usable = N <= 64 && rel == rel && abs_ == abs_ && rel < 1e-3 && abs_ < 1e30;
+        const bool usable = N <= 128 && rel == rel && abs_ == abs_ && rel < 1e-3 && abs_ < 1e30;
         S.scan_mask = usable ? 1u : 0u;
         S.drift_rel = (float)rel * 1.000001f; S.drift_abs = (float)abs_ * 1.000001f;
         if (const char* e = getenv("CRT_NO_SCAN_MASK")) if (atoi(e) != 0) S.scan_mask = 0;
@@ -547,19 +558,10 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     const uint32_t trav_threads = S.trav_waves * 64;
     ctx->lds_bytes = (size_t)S.stack_entries * trav_threads * 4 * 2;
     if (ctx->lds_bytes > 140 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");
-    if (ctx->deep) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, (trace_kernel<false, false, true>), CRT_BLOCK, ctx->lds_bytes));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, (trace_kernel<true, false, true>), CRT_BLOCK, ctx->lds_bytes));
-    } else {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, (trace_kernel<false, false, false>), CRT_BLOCK, ctx->lds_bytes));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, (trace_kernel<true, false, false>), CRT_BLOCK, ctx->lds_bytes));
-    }
+    for (int variant = 0; variant < 3; variant++)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_variant(ctx, variant == 1, variant == 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, trace_variant(ctx, false, false), CRT_BLOCK, ctx->lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu_counted, trace_variant(ctx, true, false), CRT_BLOCK, ctx->lds_bytes));
     if (ctx->blocks_per_cu < 1) ctx->blocks_per_cu = 1;
     if (ctx->blocks_per_cu_counted < 1) ctx->blocks_per_cu_counted = 1;
     {
@@ -634,10 +636,7 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
     }
     const int slot = (int)(ctx->launches % crt_ctx::kRing);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], stream));
-    if (counted)
-        launch_trace<true, false>(ctx, grid, stream, P, samples, jump, nullptr, nullptr, nullptr);
-    else
-        launch_trace<false, false>(ctx, grid, stream, P, samples, jump, nullptr, nullptr, nullptr);
+    launch_trace(ctx, counted, false, grid, stream, P, samples, jump, ctx->queue, nullptr, nullptr, nullptr, ctx->cold);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], stream));
     ctx->launches++;
@@ -692,12 +691,7 @@ int crt_render_pass_noalloc(crt_ctx* ctx, int pass_id, int samples, void* stream
     P.tile_cost = nullptr; P.tile_order = nullptr;      // storage order: the balance tables belong to crt_render_pass
     uint32_t* queue = (uint32_t*)(ws + kScratchQueueOff);
     uint32_t* state = (uint32_t*)(ws + kScratchStateOff);
-    if (ctx->deep)
-        hipLaunchKernelGGL((trace_kernel<false, false, true>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
-                           queue, ctx->stats, nullptr, nullptr, nullptr, state);
-    else
-        hipLaunchKernelGGL((trace_kernel<false, false, false>), dim3(grid), dim3(CRT_BLOCK), ctx->lds_bytes, stream, ctx->S, P, samples, jump,
-                           queue, ctx->stats, nullptr, nullptr, nullptr, state);
+    launch_trace(ctx, false, false, grid, stream, P, samples, jump, queue, nullptr, nullptr, nullptr, state);
     HIP_TRY(ctx, hipGetLastError());
     if (!async) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return CRT_OK;
@@ -824,7 +818,7 @@ int crt_primary_hits(crt_ctx* ctx, int pass_id, int32_t* node, int32_t* face, fl
     if (ctx->P.total_items) {
         HIP_TRY(ctx, hipMemset(ctx->queue, 0, 4));
         const uint32_t grid = trace_grid(ctx, ctx->blocks_per_cu);
-        launch_trace<false, true>(ctx, grid, nullptr, ctx->P, 1, jump, d.node, d.face, d.t);
+        launch_trace(ctx, false, true, grid, nullptr, ctx->P, 1, jump, ctx->queue, d.node, d.face, d.t, ctx->cold);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipDeviceSynchronize());

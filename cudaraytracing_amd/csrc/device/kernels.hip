@@ -296,13 +296,17 @@ DEV unsigned long long wave_sum(unsigned long long v) {
 // A shadow ray also leaves out the subtree of an object node that is certain to be missed, exactly as the scan
 // does for every object node it misses (trace.cu:171-185).  Bit i of the result: node i has to be tested.
 // The counted build does not scan by the mask; it checks every box hit of its full scan against it.
-DEV unsigned long long scan_candidates(const DevScene& S, const BoxPair* __restrict__ pairs, f3 pos, f3 dir, float tmax, bool shadow) {
+struct NodeMask {
+    unsigned long long lo, hi;      // bit i of lo: node i; bit i of hi: node 64 + i (scenes of 65 to 128 nodes)
+};
+
+DEV NodeMask scan_candidates(const DevScene& S, const BoxPair* __restrict__ pairs, f3 pos, f3 dir, float tmax, bool shadow) {
     const float pmax = fmaxf(fabsf(pos.x), fmaxf(fabsf(pos.y), fabsf(pos.z)));
     const float dmax = fmaxf(fabsf(dir.x), fmaxf(fabsf(dir.y), fabsf(dir.z)));
     const float dp = S.drift_rel * pmax + S.drift_abs;
     const float dd = 64.0f * (S.drift_rel * dmax);
     // anything not finite: test every node
-    if (!(pmax < 1e30f) || !(dmax < 1e30f) || !(dmax > 0.0f)) return ~0ull;
+    if (!(pmax < 1e30f) || !(dmax < 1e30f) || !(dmax > 0.0f)) return NodeMask{~0ull, ~0ull};
     const bool cx = fabsf(dir.x) >= dd && fabsf(dir.x) > 1e-30f, cy = fabsf(dir.y) >= dd && fabsf(dir.y) > 1e-30f, cz = fabsf(dir.z) >= dd && fabsf(dir.z) > 1e-30f;
     // unconstrained axis: (min - BIG) * 1 and (max + BIG) * 1 give -BIG and +BIG
     const float big = 1e37f;
@@ -341,9 +345,12 @@ DEV unsigned long long scan_candidates(const DevScene& S, const BoxPair* __restr
         return word;
     };
     const uint32_t n = S.node_count;
-    const uint32_t lo = half(0, n < 32u ? n : 32u);
-    const uint32_t hi = n > 32u ? half(32, n) : 0u;
-    return ((unsigned long long)hi << 32) | lo;
+    auto upto = [&](uint32_t limit) -> uint32_t { return n < limit ? n : limit; };
+    const uint32_t w0 = half(0, upto(32));
+    const uint32_t w1 = n > 32u ? half(32, upto(64)) : 0u;
+    const uint32_t w2 = n > 64u ? half(64, upto(96)) : 0u;
+    const uint32_t w3 = n > 96u ? half(96, upto(128)) : 0u;
+    return NodeMask{((unsigned long long)w1 << 32) | w0, ((unsigned long long)w3 << 32) | w2};
 }
 
 DEV void acc_add(float* __restrict__ p, f3 v) {
@@ -381,6 +388,7 @@ struct Lane {
     float limit;                    // slab t_max: FLT_MAX for closest hit, the light distance for shadow rays
     uint32_t node;                  // next scene node to scan
     unsigned long long mask;        // scene nodes the scan still has to test (bit i = node i), when it runs by candidates
+    unsigned long long mask_hi;     // the same for nodes 64..127 (scenes of more than 64 nodes)
     uint32_t cur;                   // BVH record to expand
     uint32_t sp;                    // LDS stack height
     uint32_t entered;               // scene node whose mesh is being traversed
@@ -481,8 +489,9 @@ DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const uint32_t* ring, b
 // run ray queries (BOX / LEAF / XFORM operations, voted per turn), the others run everything between two
 // queries of a pixel (shading, light and BSDF sampling, new camera rays, taking the next pixel from the global
 // queue).  kDeep: the BVH is deeper than the LDS stack; entries above S.stack_entries live in a per-thread
-// overflow area of the side buffer (rarely reached: a ray's stack is usually a fraction of the tree depth).
-template <bool kCount, bool kPrimary, bool kDeep>
+// overflow area of the side buffer (rarely reached: a ray's stack is usually a fraction of the tree depth).  kWide: the
+// scene has 65 to 128 nodes, so the candidate mask of the scene-node scan has a second word.
+template <bool kCount, bool kPrimary, bool kDeep, bool kWide>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(DevScene S, DevPartition P, int samples,
                                                              const uint32_t* __restrict__ jump,
                                                              uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
@@ -564,7 +573,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // the query has run out of scene nodes
         auto query_done = [&]() -> uint32_t { L.pk = L.shadow ? PK_SHADOW_CLEAR : PK_CLOSEST_DONE; return S_POST; };
         auto shadow_blocked = [&]() -> uint32_t { L.pk = PK_SHADOW_BLOCKED; return S_POST; };
-        auto first_candidate = [&]() -> uint32_t { return L.mask ? (uint32_t)__ffsll((long long)L.mask) - 1u : node_count; };
+        constexpr bool wide_mask = kWide;             // scenes of 65 to 128 nodes: the second mask word is in use
+        auto first_candidate = [&]() -> uint32_t {
+            if (L.mask) return (uint32_t)__ffsll((long long)L.mask) - 1u;
+            if (wide_mask && L.mask_hi) return 63u + (uint32_t)__ffsll((long long)L.mask_hi);
+            return node_count;
+        };
+        // bits [0, k) of a 64-bit word, for any k (k <= 0: none, k >= 64: all)
+        auto low_bits = [](int k) -> unsigned long long { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : (1ull << k) - 1ull); };
         auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_NODE : query_done(); };
 
         // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
@@ -702,15 +718,35 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 // between were certain misses; a candidate object node that a shadow ray misses takes its subtree along.
                 const uint32_t i = L.node;
                 enter_a = hitA & (sh | (tA < L.hz));
-                unsigned long long m = L.mask & ~(1ull << i);
-                if (sh & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << i) - 1ull);
-                const bool cand_b = !enter_a & (i < 63u) & (((m >> ((i + 1u) & 63u)) & 1ull) != 0);
-                enter_b = cand_b & hitB & (sh | (tB < L.hz));
-                if (cand_b) {
-                    m &= ~(2ull << i);
-                    if (sh & !hitB) m &= ~(((1ull << (after_b & 63u)) - 1ull) | (after_b >= 64u ? ~0ull : 0ull)) | ((4ull << i) - 1ull);
+                if (!wide_mask) {
+                    unsigned long long m = L.mask & ~(1ull << i);
+                    if (sh & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << i) - 1ull);
+                    const bool cand_b = !enter_a & (i < 63u) & (((m >> ((i + 1u) & 63u)) & 1ull) != 0);
+                    enter_b = cand_b & hitB & (sh | (tB < L.hz));
+                    if (cand_b) {
+                        m &= ~(2ull << i);
+                        if (sh & !hitB) m &= ~(((1ull << (after_b & 63u)) - 1ull) | (after_b >= 64u ? ~0ull : 0ull)) | ((4ull << i) - 1ull);
+                    }
+                    L.mask = m;
+                } else {
+                    // the same with two words: `drop(from, to)` clears the nodes after `from` and before `to`
+                    unsigned long long m0 = L.mask, m1 = L.mask_hi;
+                    auto clear_bit = [&](uint32_t b) { if (b < 64u) m0 &= ~(1ull << b); else m1 &= ~(1ull << (b - 64u)); };
+                    auto drop = [&](uint32_t from, uint32_t to) {
+                        m0 &= low_bits((int)from + 1) | ~low_bits((int)to);
+                        m1 &= low_bits((int)from + 1 - 64) | ~low_bits((int)to - 64);
+                    };
+                    clear_bit(i);
+                    if (sh & !hitA) drop(i, after_a);
+                    const uint32_t j = i + 1u;
+                    const bool cand_b = !enter_a & (j < 128u) & ((((j < 64u ? m0 : m1) >> (j & 63u)) & 1ull) != 0);
+                    enter_b = cand_b & hitB & (sh | (tB < L.hz));
+                    if (cand_b) {
+                        clear_bit(j);
+                        if (sh & !hitB) drop(j, after_b);
+                    }
+                    L.mask = m0; L.mask_hi = m1;
                 }
-                L.mask = m;
                 if (!(enter_a | enter_b)) {
                     L.node = first_candidate();
                     return after_scan();
@@ -727,7 +763,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     if (S.scan_mask) {
                         const bool chk_a = obj_a & hitA, chk_b = look_b & obj_b & hitB;
                         tally.scan_checks += (chk_a ? 1u : 0u) + (chk_b ? 1u : 0u);
-                        tally.scan_violations += ((chk_a && !((L.mask >> (L.node & 63u)) & 1ull)) ? 1u : 0u) + ((chk_b && !((L.mask >> ((L.node + 1u) & 63u)) & 1ull)) ? 1u : 0u);
+                        auto is_candidate = [&](uint32_t b) -> bool { return (((b < 64u ? L.mask : L.mask_hi) >> (b & 63u)) & 1ull) != 0; };
+                        tally.scan_violations += ((chk_a && !is_candidate(L.node)) ? 1u : 0u) + ((chk_b && !is_candidate(L.node + 1u)) ? 1u : 0u);
                     }
                 }
                 if (!(enter_a | enter_b)) {
@@ -833,6 +870,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 L.qinv = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
                 L.node = c.w;
                 L.mask = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
+                if (kWide) L.mask_hi = (unsigned long long)d.z | ((unsigned long long)d.w << 32);
                 L.trav = false; L.pend = 0;
                 L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
                 // no node of the scene can be hit at all: the query is over before its first box step
@@ -1296,18 +1334,18 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (fresh) rec[kRecPath + 26] = tile;
             if (result == R_RAY) {
                 // one pass over the node boxes for the query the slot is about to start
-                unsigned long long mask = ~0ull;
+                NodeMask mask = {~0ull, ~0ull};
                 uint32_t node = 0;
                 if (S.scan_mask) {
                     mask = scan_candidates(S, pairs, rpos, rdir, rlimit, rshadow);
-                    if (by_mask) node = mask ? (uint32_t)__ffsll((long long)mask) - 1u : node_count;
+                    if (by_mask) node = mask.lo ? (uint32_t)__ffsll((long long)mask.lo) - 1u : (mask.hi ? 63u + (uint32_t)__ffsll((long long)mask.hi) : node_count);
                 }
                 const f3 rinv = recip3(rdir);
                 uint4* ray4 = reinterpret_cast<uint4*>(rec + kRecRay);
                 ray4[0] = uint4{__float_as_uint(rpos.x), __float_as_uint(rpos.y), __float_as_uint(rpos.z), __float_as_uint(rlimit)};
                 ray4[1] = uint4{__float_as_uint(rdir.x), __float_as_uint(rdir.y), __float_as_uint(rdir.z), rshadow ? 1u : 0u};
                 ray4[2] = uint4{__float_as_uint(rinv.x), __float_as_uint(rinv.y), __float_as_uint(rinv.z), node};
-                ray4[3] = uint4{(uint32_t)mask, (uint32_t)(mask >> 32), 0u, 0u};
+                ray4[3] = uint4{(uint32_t)mask.lo, (uint32_t)(mask.lo >> 32), (uint32_t)mask.hi, (uint32_t)(mask.hi >> 32)};
             } else {
                 rec[kRecHit] = PK_FETCH;
             }

@@ -387,7 +387,8 @@ def test_renderer_front_end(gpu_ctx, tmp_path):
 
 @pytest.mark.parametrize("name,w,h,spp", [("final_frame0042", 384, 216, 4), ("proj5_box", 320, 180, 4), ("proj7_checkerboard", 320, 180, 8),
                                            ("proj4_box", 320, 180, 4), ("teapot_low_box", 640, 360, 2), ("final_frame0001", 256, 144, 2),
-                                           ("proj13_box", 320, 180, 4), ("proj1_snowman", 320, 180, 2), ("proj5_plane", 320, 180, 4)])
+                                           ("proj13_box", 320, 180, 4), ("proj1_snowman", 320, 180, 2), ("proj5_plane", 320, 180, 4),
+                                           ("proj5_glasspot", 640, 360, 4)])
 def test_scan_candidate_mask_never_drops_a_hit(gpu_ctx, name, w, h, spp):
     """The plain kernels scan only the scene nodes a conservative test cannot rule out.  The counted kernel scans
     every node, as the reference does, and checks each box it finds hit against that mask: no violation may occur,
@@ -407,7 +408,7 @@ def test_scan_candidate_mask_never_drops_a_hit(gpu_ctx, name, w, h, spp):
     assert st["checks"] > 0 and st["violations"] == 0
 
 
-def _nested_scene_xml(seed):
+def _nested_scene_xml(seed, tops=5):
     """A scene graph three levels deep: object nodes with object children (the scan's subtree skip for shadow rays),
     rotations and non-uniform scales (ray drift through ToLocal / FromLocal), planes and spheres, two point lights."""
     rs = np.random.RandomState(seed)
@@ -426,7 +427,7 @@ def _nested_scene_xml(seed):
         out.append("</object>")
         return out
     body = []
-    for k in range(5):
+    for k in range(tops):
         body += obj(0, k)
     body.append('<object type="plane" name="floor" material="m0"><scale value="40"/><translate z="-8"/></object>')
     mats = ['<material type="blinn" name="m0"><diffuse r="0.8" g="0.7" b="0.6"/><specular value="0.2"/><glossiness value="20"/></material>',
@@ -440,12 +441,14 @@ def _nested_scene_xml(seed):
     return "<xml><scene>" + "".join(body + mats + lights) + "</scene>" + cam + "</xml>"
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_nested_scene_graph_is_bit_exact(gpu_ctx, tmp_path, seed):
+@pytest.mark.parametrize("seed,tops,lo,hi", [(1, 5, 20, 64), (2, 5, 20, 64), (3, 5, 20, 64), (4, 13, 64, 128), (5, 14, 64, 128)])
+def test_nested_scene_graph_is_bit_exact(gpu_ctx, tmp_path, seed, tops, lo, hi):
+    """Seeds 4 and 5 build graphs of 65 to 128 nodes: the candidate mask then has two words, and subtrees that a
+    shadow ray skips straddle the word boundary."""
     xml = tmp_path / f"nested{seed}.xml"
-    xml.write_text(_nested_scene_xml(seed))
+    xml.write_text(_nested_scene_xml(seed, tops))
     s = crt.Scene.load_xml(str(xml))
-    assert 20 < s.desc().node_count <= 64
+    assert lo < s.desc().node_count <= hi, s.desc().node_count
     flat = str(tmp_path / f"nested{seed}.crtscene")
     s.save_file(flat)
     o = orc.OracleScene(flat)
