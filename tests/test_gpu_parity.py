@@ -468,3 +468,61 @@ def test_nested_scene_graph_is_bit_exact(gpu_ctx, tmp_path, seed, tops, lo, hi):
     assert chk["checks"] > 0 and chk["violations"] == 0
     full = gpu_ctx.stats(); full.pop("texel_quads"); cnt.pop("texel_quads")
     assert full == cnt
+
+
+def _extreme_scene_xml(case):
+    """Transforms that stress the drift bound behind the candidate mask: very unequal scales (ill-conditioned round
+    trips through ToLocal / FromLocal), the whole scene far from the origin (large |p|), and many rotated nodes whose
+    summed bound approaches the cut-off above which the mask is switched off."""
+    rs = np.random.RandomState(100 + case)
+    off = {0: (0.0, 0.0, 0.0), 1: (1.0e5, -2.0e5, 5.0e4), 2: (0.0, 0.0, 0.0)}[case]
+    body = []
+    count = 60 if case == 2 else 18
+    for k in range(count):
+        kind = "plane" if k % 5 == 4 else "sphere"
+        if case == 0:
+            sc = [10.0 ** rs.uniform(-2, 1.2) for _ in range(3)]          # ratios up to 1600 within one node
+        else:
+            sc = list(rs.uniform(0.5, 2.5, 3))
+        t = rs.uniform(-9, 9, 3) + np.array(off)
+        axis = rs.uniform(-1, 1, 3)
+        body.append(f'<object type="{kind}" name="o{k}" material="m{k % 3}">'
+                    f'<scale x="{sc[0]:.6g}" y="{sc[1]:.6g}" z="{sc[2]:.6g}"/>'
+                    f'<rotate angle="{rs.uniform(0, 360):.3f}" x="{axis[0]:.4f}" y="{axis[1]:.4f}" z="{axis[2]:.4f}"/>'
+                    f'<translate x="{t[0]:.9g}" y="{t[1]:.9g}" z="{t[2]:.9g}"/></object>')
+    body.append(f'<object type="plane" name="floor" material="m0"><scale value="60"/><translate x="{off[0]:.9g}" y="{off[1]:.9g}" z="{off[2] - 10:.9g}"/></object>')
+    mats = ['<material type="blinn" name="m0"><diffuse r="0.8" g="0.7" b="0.6"/><specular value="0.2"/><glossiness value="20"/></material>',
+            '<material type="blinn" name="m1"><diffuse r="0.2" g="0.5" b="0.8"/><specular value="0.7"/><glossiness value="60"/></material>',
+            '<material type="blinn" name="m2"><diffuse value="0.05"/><specular value="0.1"/><glossiness value="100"/>'
+            '<refraction value="0.85" index="1.5"/></material>']
+    lights = [f'<light type="point" name="l0"><intensity value="600"/><position x="{off[0] + 10:.9g}" y="{off[1] - 12:.9g}" z="{off[2] + 14:.9g}"/><size value="2"/></light>']
+    cam = (f'<camera><position x="{off[0]:.9g}" y="{off[1] - 30:.9g}" z="{off[2] + 9:.9g}"/><target x="{off[0]:.9g}" y="{off[1]:.9g}" z="{off[2] - 1:.9g}"/>'
+           '<up x="0" y="0" z="1"/><fov value="42"/><width value="224"/><height value="140"/></camera>')
+    return "<xml><scene>" + "".join(body + mats + lights) + "</scene>" + cam + "</xml>"
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_candidate_mask_under_extreme_transforms(gpu_ctx, tmp_path, case):
+    """Whether the mask is in use for such a scene is the upload's decision (it is switched off when the drift bound is
+    too large to be useful); either way the plain kernel must equal the oracle, and where the mask is on, the counted
+    kernel's check of every box hit against it must find no violation."""
+    xml = tmp_path / f"extreme{case}.xml"
+    xml.write_text(_extreme_scene_xml(case))
+    s = crt.Scene.load_xml(str(xml))
+    flat = str(tmp_path / f"extreme{case}.crtscene")
+    s.save_file(flat)
+    o = orc.OracleScene(flat)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, 3)
+    acc = gpu_ctx.read_accumulators()
+    ref, cnt = o.render(0, 3, count=True)
+    for k, n in enumerate(("results", "normals", "albedos")):
+        assert same(acc[k], ref[k]), n
+    st = gpu_ctx.stats()
+    assert (st["closest_rays"], st["shadow_rays"]) == (cnt["closest_rays"], cnt["shadow_rays"])
+    gpu_ctx.clear()
+    gpu_ctx.render_pass_counted(0, 3)
+    assert same(gpu_ctx.read_accumulators()[0], ref[0])
+    assert gpu_ctx.scan_check()["violations"] == 0
+
