@@ -307,14 +307,14 @@ def main():
         if synthetic:
             # The checker builds its BVH with the reference's own algorithm (every split rescans the node's elements 93
             # times), which takes hours on ten million triangles: the CPU sample is the same generator with 64 of the
-            # copies, at a quarter of the width and of the height, 1 spp.
+            # copies, at a quarter of the width and of the height, ten times --cpu-spp samples.
             import tempfile
             few = min(args.copies, 64)
             with tempfile.TemporaryDirectory() as tmp:
                 small = crt.Scene.load_file(scene_file).make_instanced(0, few, 1, W // 4, H // 4)
                 path = os.path.join(tmp, "synthetic.crtscene")
                 small.save_file(path)
-                cpu = cpu_baseline(path, f"synthetic scene with {few} of the {args.copies} copies", W // 4, H // 4, 16, args.spp, threads)
+                cpu = cpu_baseline(path, f"synthetic scene with {few} of the {args.copies} copies", W // 4, H // 4, min(args.spp, 10 * args.cpu_spp), args.spp, threads)
                 cpu["ms_per_frame_extrapolated"] = None     # a smaller scene: its rate is the baseline, a frame time would not be
         else:
             cpu = cpu_baseline(scene_file, scene_label, W, H, args.cpu_spp, args.spp, threads)
