@@ -393,7 +393,7 @@ struct Lane {
     uint32_t sp;                    // LDS stack height
     uint32_t entered;               // scene node whose mesh is being traversed
     uint32_t pend;                  // LEAF: remaining leaf range; NODE: kPendExit when a mesh has to be left first
-    bool shadow, trav, mesh_hit;
+    bool shadow, mesh_hit;
     // closest hit so far; normal / texture coordinates are derived from (h_*) when the query ends
     float hz;
     f3 hpos;                        // world space
@@ -583,12 +583,26 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         auto low_bits = [](int k) -> unsigned long long { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : (1ull << k) - 1ull); };
         auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_NODE : query_done(); };
 
+        // The query is through with the object of node `entered` and its ray is still in that node's space.  When the
+        // scan has a further node to look at, the next NODE turn takes the ray back to world space first.  When it has
+        // none, the query is over: a shadow query's ray is of no further use, and a closest-hit query posts its result
+        // with the ray as it is; the shading wave that takes the result does the way back (same operations), with all
+        // of its lanes busy instead of the few a traversal turn would have for it.
+        auto walk_ended = [&]() -> uint32_t {
+            L.pend = kPendExit;
+            const uint32_t next = by_mask ? first_candidate() : L.entered + 1u;
+            if (next < node_count) return S_NODE;
+            if (L.shadow) { L.pend = 0; return query_done(); }
+            L.pk = PK_CLOSEST_DONE;
+            return S_POST;
+        };
+
         // pop until an interior node that survives the distance cull, a non-empty leaf, or an empty stack
         // (MeshObject::Traverse / TraverseShadow loop heads, scene/objects.cu:184-196, 231-242)
         auto resolve = [&](bool have_next, uint32_t next_ref, float next_t) -> uint32_t {
             for (;;) {
                 if (!have_next) {
-                    if (L.sp == 0) { L.pend = kPendExit; return S_NODE; }
+                    if (L.sp == 0) return walk_ended();
                     L.sp--;
                     stack_get(L.sp, next_ref, next_t);
                 }
@@ -684,24 +698,26 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // Node::ToLocal, then the sphere / plane test in place or the start of a BVH walk (trace.cu:61-66, 188-191;
         // objects.cu:7-159).
         auto op_node = [&]() -> uint32_t {
-            if (L.pend == kPendExit) {
-                const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + L.entered);
-                const float4 r3 = xp[3], r4 = xp[4], r5 = xp[5];
+            // Which node is looked at does not depend on the way back, so the forward matrix of the node being left and
+            // the box record of the next node are fetched together (lanes that leave nothing read the record of node 0,
+            // one address for all of them).
+            const bool leaving = L.pend == kPendExit;
+            if (leaving) L.node = by_mask ? first_candidate() : L.entered + 1;      // (a further node exists: walk_ended)
+            const float4* __restrict__ lp = reinterpret_cast<const float4*>(S.xf + (leaving ? L.entered : 0u));
+            const float4* rp = reinterpret_cast<const float4*>(pairs + L.node);
+            const float4 r3 = lp[3], r4 = lp[4], r5 = lp[5];
+            const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            if (leaving) {
                 const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
                 if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
-                L.trav = false;
                 L.pend = 0;
                 xform_ray(tm, L.pdx, L.pdy, L.pdz);
                 L.qinv = recip3(L.qdir());
-                L.node = by_mask ? first_candidate() : L.entered + 1;
-                if (L.node >= node_count) return query_done();
             }
             // node `node` is half A of its record, node + 1 is half B.  Closest hit enters a node whose box is
             // hit nearer than the current hit; a shadow ray enters on any box hit and skips the whole
             // subtree of a node with an object whose box it misses (trace.cu:171-185).
             // (The half after the last node of an odd list is a dummy without an object and with an empty box.)
-            const float4* rp = reinterpret_cast<const float4*>(pairs + L.node);
-            const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
             const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
             float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
             float dA, dB;
@@ -774,17 +790,15 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             }
             const uint32_t idx = enter_a ? L.node : L.node + 1u;
             const uint32_t kind = enter_a ? kind_a : kind_b;
-            // the whole 112-byte record is fetched at once (both matrices and the tags) so that no further
-            // memory round trip follows the object test
+            // the inverse matrix and the tags of the node's record; the forward matrix is fetched when the node is left
             const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
-            const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r3 = xp[3], r4 = xp[4], r5 = xp[5], r6 = xp[6];
+            const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r6 = xp[6];
             const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-            const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
             TALLY(node_enters);
             xform_ray(itm, L.pdx, L.pdy, L.pdz);
             if (kind == CRT_OBJ_MESH) {
                 L.qinv = recip3(L.qdir());
-                L.trav = true; L.entered = idx; L.sp = 0; L.mesh_hit = false;
+                L.entered = idx; L.sp = 0; L.mesh_hit = false;
                 return resolve(true, __float_as_uint(r6.x), 0.0f);
             }
             const f3 pos = L.qpos(), dir = L.qdir();
@@ -817,19 +831,18 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     }
                 }
             }
+            L.entered = idx;
+            L.mesh_hit = false;
             if (got) {
                 if (L.shadow) return shadow_blocked();
                 const f3 p = pos + t * dir;
                 L.hz = t;
-                L.hpos = xform_point(tm, p);
+                L.mesh_hit = true;            // the world position follows when the node is left, as after a BVH walk
                 L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
                 L.h_node = idx; L.h_front = front;
                 L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
             }
-            xform_ray(tm, L.pdx, L.pdy, L.pdz);
-            L.qinv = recip3(L.qdir());
-            L.node = by_mask ? first_candidate() : idx + 1;
-            return after_scan();
+            return walk_ended();
         };
 
         // ---- EXCHANGE: lanes whose query has ended write its result into their slot and queue the slot for
@@ -845,7 +858,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     r4[0] = uint4{L.pk, __float_as_uint(L.hz), L.h_kind | (L.h_front ? 4u : 0u) | (L.h_node << 3), L.h_c};
                     r4[1] = uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), __float_as_uint(L.h_a)};
                     r4[2] = uint4{__float_as_uint(qp.x), __float_as_uint(qp.y), __float_as_uint(qp.z), __float_as_uint(L.h_b)};
-                    r4[3] = uint4{__float_as_uint(qd.x), __float_as_uint(qd.y), __float_as_uint(qd.z), 0u};
+                    // last word: 0, or the node whose space the ray (and a hit found in it) is still in: node + 1, bit 31 = hit found there
+                    const uint32_t inside = L.pend == kPendExit ? ((L.entered + 1u) | (L.mesh_hit ? 0x80000000u : 0u)) : 0u;
+                    r4[3] = uint4{__float_as_uint(qd.x), __float_as_uint(qd.y), __float_as_uint(qd.z), inside};
                 } else {
                     rec[0] = L.pk;
                 }
@@ -871,7 +886,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 L.node = c.w;
                 L.mask = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
                 if (kWide) L.mask_hi = (unsigned long long)d.z | ((unsigned long long)d.w << 32);
-                L.trav = false; L.pend = 0;
+                L.pend = 0;
                 L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
                 // no node of the scene can be hit at all: the query is over before its first box step
                 state = after_scan();
@@ -1052,6 +1067,17 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 const float h_a = __uint_as_float(h1.w), h_b = __uint_as_float(h2.w);
                 qpos = mk3(__uint_as_float(h2.x), __uint_as_float(h2.y), __uint_as_float(h2.z));
                 qdir = mk3(__uint_as_float(h3.x), __uint_as_float(h3.y), __uint_as_float(h3.z));
+                if (h3.w != 0) {
+                    // the query ended inside a node: world position of a hit found there and Node::FromLocal for the
+                    // ray (trace.cu:64-66), exactly as a NODE turn of the traversal waves does it
+                    const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + ((h3.w & 0x7fffffffu) - 1u));
+                    const float4 r3 = xp[3], r4 = xp[4], r5 = xp[5];
+                    const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
+                    if (h3.w & 0x80000000u) hpos = xform_point(tm, qpos + hz * qdir);
+                    f2 px = f2{qpos.x, qdir.x}, py = f2{qpos.y, qdir.y}, pz = f2{qpos.z, qdir.z};
+                    xform_ray(tm, px, py, pz);
+                    qpos = mk3(px.x, py.x, pz.x); qdir = mk3(px.y, py.y, pz.y);
+                }
                 if (kCount && lane_rank(__ballot(true)) == 0) sect_clock[wave] = __builtin_amdgcn_s_memtime();
 
                 // lights are intersected last, with the ray as the node loop left it (trace.cu:72-78)
