@@ -285,7 +285,7 @@ TraceKernel trace_variant(bool deep, bool wide) {
 }
 
 TraceKernel trace_variant(const crt_ctx* ctx, bool counted, bool primary) {
-    const bool wide = ctx->S.node_count > 64;
+    const bool wide = ctx->S.node_count > 64;      // two mask words: 65 to 128 nodes, or groups of nodes beyond that
     if (primary) return trace_variant<false, true>(ctx->deep, wide);
     return counted ? trace_variant<true, false>(ctx->deep, wide) : trace_variant<false, false>(ctx->deep, wide);
 }
@@ -468,6 +468,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
 
     DevScene& S = ctx->S;
     memset(&S, 0, sizeof S);
+    std::vector<BoxPair> group_pairs(1);
     const crt_camera& cam = d->camera;
     S.width = cam.width; S.height = cam.height;
     memcpy(S.cam_pos, cam.position, 12); S.dof = cam.dof; S.pixel_size = cam.pixel_size;
@@ -515,8 +516,36 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
             abs_ += nrt + 9.0 * u * (nat + nt);
         }
         rel *= 1.05; abs_ *= 1.05;
-        const bool usable = N <= 128 && rel == rel && abs_ == abs_ && rel < 1e-3 && abs_ < 1e30;
-        S.scan_mask = usable ? 1u : 0u;
+        // (the 5 % assume that |p| grows by less than that along a query: exp(rel) - 1 does, far below either limit)
+        const bool grouped = N > 128;
+        const bool usable = rel == rel && abs_ == abs_ && rel < (grouped ? 1e-2 : 1e-3) && abs_ < 1e30;
+        S.scan_mask = usable ? (grouped ? 5u : 1u) : 0u;
+        if (grouped) {
+            // One mask bit per group of 2^shift consecutive nodes, at most 128 groups; a group's box is the union of
+            // the boxes of its object nodes (a group without one is never a candidate).
+            uint32_t shift = 1;
+            while (((N + (1u << shift) - 1) >> shift) > 128) shift++;
+            const uint32_t G = (N + (1u << shift) - 1) >> shift;
+            S.group_shift = shift; S.group_count = G;
+            group_pairs.assign(G, BoxPair{});
+            auto group_half = [&](uint32_t g, float* bmin, float* bmax, uint32_t& ref) {
+                for (int k = 0; k < 3; k++) { bmin[k] = CRT_BIGFLOAT; bmax[k] = -CRT_BIGFLOAT; }
+                bool any = false;
+                for (uint32_t i = g << shift; g < G && i < N && i < ((g + 1) << shift); i++) {
+                    if (d->nodes[i].object_kind == CRT_OBJ_NONE) continue;
+                    any = true;
+                    for (int k = 0; k < 3; k++) { bmin[k] = fminf(bmin[k], d->nodes[i].box_min[k]); bmax[k] = fmaxf(bmax[k], d->nodes[i].box_max[k]); }
+                }
+                ref = (any ? (uint32_t)CRT_OBJ_SPHERE : (uint32_t)CRT_OBJ_NONE) | ((g + 1) << 2);
+            };
+            for (uint32_t g = 0; g < G; g++) {
+                BoxPair& p = group_pairs[g];
+                float lo[3], hi[3];
+                group_half(g, lo, hi, p.ref_a); set_box(p.a, lo, hi);
+                group_half(g + 1, lo, hi, p.ref_b); set_box(p.b, lo, hi);
+                p.aux_a = p.aux_b = 0;
+            }
+        }
         S.drift_rel = (float)rel * 1.000001f; S.drift_abs = (float)abs_ * 1.000001f;
         if (const char* e = getenv("CRT_NO_SCAN_MASK")) if (atoi(e) != 0) S.scan_mask = 0;
         // profiling only: the counted build then scans by the mask too (its node counters no longer match the reference's)
@@ -538,7 +567,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     { const char* e = getenv("CRT_NO_BALANCE"); ctx->no_balance = e && atoi(e) != 0; }
     if ((rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, xf, &S.xf)) ||
         (rc = upload(ctx, attrs, &S.attrs)) || (rc = upload(ctx, materials, &S.materials)) ||
-        (rc = upload(ctx, textures, &S.textures)) || (rc = upload(ctx, texels, &S.texels)) || (rc = upload(ctx, lights, &S.lights)))
+        (rc = upload(ctx, textures, &S.textures)) || (rc = upload(ctx, texels, &S.texels)) || (rc = upload(ctx, lights, &S.lights)) ||
+        (rc = upload(ctx, group_pairs, &S.group_pairs)))
         return rc;
 
     const size_t px = (size_t)cam.width * cam.height;

@@ -126,8 +126,12 @@ struct DevScene {
     // Candidate mask of the scene-node scan (see scan_candidates in kernels.hip).  drift_rel / drift_abs bound how
     // far a ray can move over one whole query through the ToLocal / FromLocal round trips of the nodes it enters:
     // |pos' - pos| <= drift_rel * max|pos| + drift_abs, |dir' - dir| <= drift_rel * max|dir| (per component).
-    uint32_t scan_mask;              // bit 0: the plain kernels scan candidates only (node_count <= 64 and small drift)
+    // Scenes of more than 128 nodes: bit g of the mask stands for the group of 2^group_shift consecutive nodes
+    // starting at node g << group_shift (group_pairs: the boxes of the groups, laid out like the node records).
+    uint32_t scan_mask;              // bit 0: a candidate mask is in use (small drift); bit 1: the counting build follows it too (profiling); bit 2: its bits are groups of nodes
+    uint32_t group_shift, group_count;
     float drift_rel, drift_abs;
+    const BoxPair* group_pairs;
     const BoxPair* pairs;
     const TriRec* tris;
     const NodeXf* xf;

@@ -296,11 +296,14 @@ DEV unsigned long long wave_sum(unsigned long long v) {
 // A shadow ray also leaves out the subtree of an object node that is certain to be missed, exactly as the scan
 // does for every object node it misses (trace.cu:171-185).  Bit i of the result: node i has to be tested.
 // The counted build does not scan by the mask; it checks every box hit of its full scan against it.
+// Scenes of more than 128 nodes run the same test over the boxes of groups of consecutive nodes (`pairs` is then the
+// table of group boxes, `n` their number, no subtree rule): the scan walks the nodes of candidate groups one by one,
+// as the reference does, and passes over the other groups.
 struct NodeMask {
     unsigned long long lo, hi;      // bit i of lo: node i; bit i of hi: node 64 + i (scenes of 65 to 128 nodes)
 };
 
-DEV NodeMask scan_candidates(const DevScene& S, const BoxPair* __restrict__ pairs, f3 pos, f3 dir, float tmax, bool shadow) {
+DEV NodeMask scan_candidates(const DevScene& S, const BoxPair* __restrict__ pairs, uint32_t n, f3 pos, f3 dir, float tmax, bool shadow) {
     const float pmax = fmaxf(fabsf(pos.x), fmaxf(fabsf(pos.y), fabsf(pos.z)));
     const float dmax = fmaxf(fabsf(dir.x), fmaxf(fabsf(dir.y), fabsf(dir.z)));
     const float dp = S.drift_rel * pmax + S.drift_abs;
@@ -344,7 +347,6 @@ DEV NodeMask scan_candidates(const DevScene& S, const BoxPair* __restrict__ pair
         }
         return word;
     };
-    const uint32_t n = S.node_count;
     auto upto = [&](uint32_t limit) -> uint32_t { return n < limit ? n : limit; };
     const uint32_t w0 = half(0, upto(32));
     const uint32_t w1 = n > 32u ? half(32, upto(64)) : 0u;
@@ -526,7 +528,13 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const uint32_t node_count = S.node_count;
     // the plain kernels scan the candidate nodes only; the counted one scans every node, as the reference does, and
     // checks its box hits against the mask
-    const bool by_mask = S.scan_mask != 0 && (!kCount || (S.scan_mask & 2u) != 0);      // bit 1: profiling, the counted build follows the mask too
+    const bool follow_mask = S.scan_mask != 0 && (!kCount || (S.scan_mask & 2u) != 0);      // bit 1: profiling, the counted build follows the mask too
+    // mask bits are groups of nodes (more than 128 nodes); such scenes always run the kernel variant with two mask
+    // words, so the one-word variant carries none of the code for it
+    const bool grouped = kWide && (S.scan_mask & 4u) != 0;
+    const bool by_mask = follow_mask && !grouped;
+    const bool by_group = follow_mask && grouped;
+    const uint32_t group_shift = S.group_shift;
 
     Tally tally = {};
     // counted build: when the wave started / first found the pixel queue dry (per wave, in LDS)
@@ -582,6 +590,16 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // bits [0, k) of a 64-bit word, for any k (k <= 0: none, k >= 64: all)
         auto low_bits = [](int k) -> unsigned long long { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : (1ull << k) - 1ull); };
         auto after_scan = [&]() -> uint32_t { return L.node < node_count ? (uint32_t)S_NODE : query_done(); };
+        // scan by groups: node n if its group is a candidate, else the first node of the next candidate group
+        auto next_from = [&](uint32_t n) -> uint32_t {
+            if (!by_group || n >= node_count) return n;
+            const uint32_t g = n >> group_shift;
+            const unsigned long long lo = L.mask & ~low_bits((int)g);
+            const unsigned long long hi = wide_mask ? (L.mask_hi & ~low_bits((int)g - 64)) : 0ull;
+            const uint32_t first = lo ? (uint32_t)__ffsll((long long)lo) - 1u : (hi ? 63u + (uint32_t)__ffsll((long long)hi) : 0xffffffffu);
+            if (first == g) return n;
+            return first == 0xffffffffu ? node_count : first << group_shift;
+        };
 
         // The query is through with the object of node `entered` and its ray is still in that node's space.  When the
         // scan has a further node to look at, the next NODE turn takes the ray back to world space first.  When it has
@@ -590,7 +608,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // of its lanes busy instead of the few a traversal turn would have for it.
         auto walk_ended = [&]() -> uint32_t {
             L.pend = kPendExit;
-            const uint32_t next = by_mask ? first_candidate() : L.entered + 1u;
+            const uint32_t next = by_mask ? first_candidate() : next_from(L.entered + 1u);
             if (next < node_count) return S_NODE;
             if (L.shadow) { L.pend = 0; return query_done(); }
             L.pk = PK_CLOSEST_DONE;
@@ -702,7 +720,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // the box record of the next node are fetched together (lanes that leave nothing read the record of node 0,
             // one address for all of them).
             const bool leaving = L.pend == kPendExit;
-            if (leaving) L.node = by_mask ? first_candidate() : L.entered + 1;      // (a further node exists: walk_ended)
+            if (leaving) L.node = by_mask ? first_candidate() : next_from(L.entered + 1u);      // (a further node exists: walk_ended)
             const float4* __restrict__ lp = reinterpret_cast<const float4*>(S.xf + (leaving ? L.entered : 0u));
             const float4* rp = reinterpret_cast<const float4*>(pairs + L.node);
             const float4 r3 = lp[3], r4 = lp[4], r5 = lp[5];
@@ -779,12 +797,12 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     if (S.scan_mask) {
                         const bool chk_a = obj_a & hitA, chk_b = look_b & obj_b & hitB;
                         tally.scan_checks += (chk_a ? 1u : 0u) + (chk_b ? 1u : 0u);
-                        auto is_candidate = [&](uint32_t b) -> bool { return (((b < 64u ? L.mask : L.mask_hi) >> (b & 63u)) & 1ull) != 0; };
+                        auto is_candidate = [&](uint32_t node) -> bool { const uint32_t b = grouped ? node >> group_shift : node; return (((b < 64u ? L.mask : L.mask_hi) >> (b & 63u)) & 1ull) != 0; };
                         tally.scan_violations += ((chk_a && !is_candidate(L.node)) ? 1u : 0u) + ((chk_b && !is_candidate(L.node + 1u)) ? 1u : 0u);
                     }
                 }
                 if (!(enter_a | enter_b)) {
-                    L.node = jump_a ? after_a : ((sh & obj_b) ? after_b : L.node + 2);
+                    L.node = next_from(jump_a ? after_a : ((sh & obj_b) ? after_b : L.node + 2));
                     return after_scan();
                 }
             }
@@ -1363,8 +1381,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 NodeMask mask = {~0ull, ~0ull};
                 uint32_t node = 0;
                 if (S.scan_mask) {
-                    mask = scan_candidates(S, pairs, rpos, rdir, rlimit, rshadow);
-                    if (by_mask) node = mask.lo ? (uint32_t)__ffsll((long long)mask.lo) - 1u : (mask.hi ? 63u + (uint32_t)__ffsll((long long)mask.hi) : node_count);
+                    mask = grouped ? scan_candidates(S, S.group_pairs, S.group_count, rpos, rdir, rlimit, false)
+                                   : scan_candidates(S, pairs, node_count, rpos, rdir, rlimit, rshadow);
+                    const uint32_t first = mask.lo ? (uint32_t)__ffsll((long long)mask.lo) - 1u : (mask.hi ? 63u + (uint32_t)__ffsll((long long)mask.hi) : 0xffffffffu);
+                    if (by_mask) node = first < node_count ? first : node_count;
+                    if (by_group) node = first < S.group_count ? first << group_shift : node_count;
                 }
                 const f3 rinv = recip3(rdir);
                 uint4* ray4 = reinterpret_cast<uint4*>(rec + kRecRay);

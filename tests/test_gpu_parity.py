@@ -441,10 +441,12 @@ def _nested_scene_xml(seed, tops=5):
     return "<xml><scene>" + "".join(body + mats + lights) + "</scene>" + cam + "</xml>"
 
 
-@pytest.mark.parametrize("seed,tops,lo,hi", [(1, 5, 20, 64), (2, 5, 20, 64), (3, 5, 20, 64), (4, 13, 64, 128), (5, 14, 64, 128)])
+@pytest.mark.parametrize("seed,tops,lo,hi", [(1, 5, 20, 64), (2, 5, 20, 64), (3, 5, 20, 64), (4, 13, 64, 128), (5, 14, 64, 128),
+                                             (6, 30, 128, 256), (7, 75, 256, 1024)])
 def test_nested_scene_graph_is_bit_exact(gpu_ctx, tmp_path, seed, tops, lo, hi):
     """Seeds 4 and 5 build graphs of 65 to 128 nodes: the candidate mask then has two words, and subtrees that a
-    shadow ray skips straddle the word boundary."""
+    shadow ray skips straddle the word boundary.  Seeds 6 and 7 build graphs of more than 128 nodes: a mask bit then
+    stands for a group of 2 or 8 consecutive nodes, and subtrees straddle group boundaries."""
     xml = tmp_path / f"nested{seed}.xml"
     xml.write_text(_nested_scene_xml(seed, tops))
     s = crt.Scene.load_xml(str(xml))
@@ -525,4 +527,75 @@ def test_candidate_mask_under_extreme_transforms(gpu_ctx, tmp_path, case):
     gpu_ctx.render_pass_counted(0, 3)
     assert same(gpu_ctx.read_accumulators()[0], ref[0])
     assert gpu_ctx.scan_check()["violations"] == 0
+
+
+def _instance_grid_xml(tmp_path, n_side):
+    """n_side x n_side instances of one small mesh (one BVH shared by all of them), each rotated and scaled on its own,
+    over a floor: the scene-node list is far longer than the candidate mask has bits."""
+    rs = np.random.RandomState(11)
+    # a bumpy octahedron, subdivided twice (128 triangles)
+    verts = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    faces = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    for _ in range(2):
+        mid, out = {}, []
+        def midpoint(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in mid:
+                m = np.add(verts[a], verts[b]) * 0.5
+                verts.append(tuple(m / np.linalg.norm(m)))
+                mid[key] = len(verts) - 1
+            return mid[key]
+        for a, b, c in faces:
+            ab, bc, ca = midpoint(a, b), midpoint(b, c), midpoint(c, a)
+            out += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+        faces = out
+    verts = [tuple(np.array(v) * (1 + 0.15 * rs.rand())) for v in verts]
+    (tmp_path / "blob.obj").write_text("".join(f"v {x:.6f} {y:.6f} {z:.6f}\n" for x, y, z in verts) +
+                                       "".join(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in faces))
+    body = []
+    for j in range(n_side):
+        for i in range(n_side):
+            sc = rs.uniform(0.25, 0.45, 3)
+            axis = rs.uniform(-1, 1, 3)
+            body.append(f'<object type="obj" name="blob.obj" material="m{(i + j) % 3}">'
+                        f'<scale x="{sc[0]:.4f}" y="{sc[1]:.4f}" z="{sc[2]:.4f}"/>'
+                        f'<rotate angle="{rs.uniform(0, 360):.2f}" x="{axis[0]:.3f}" y="{axis[1]:.3f}" z="{axis[2]:.3f}"/>'
+                        f'<translate x="{i - n_side / 2 + 0.5:.3f}" y="{j - n_side / 2 + 0.5:.3f}" z="{0.5 + 0.4 * rs.rand():.3f}"/></object>')
+    body.append(f'<object type="plane" name="floor" material="m0"><scale value="{n_side}"/></object>')
+    mats = ['<material type="blinn" name="m0"><diffuse r="0.8" g="0.7" b="0.6"/><specular value="0.2"/><glossiness value="20"/></material>',
+            '<material type="blinn" name="m1"><diffuse r="0.2" g="0.5" b="0.8"/><specular value="0.7"/><glossiness value="60"/></material>',
+            '<material type="blinn" name="m2"><diffuse value="0.05"/><specular value="0.1"/><glossiness value="100"/>'
+            '<refraction value="0.85" index="1.5"/></material>']
+    lights = [f'<light type="point" name="l0"><intensity value="{30 * n_side * n_side}"/><position x="{0.3 * n_side}" y="{-0.4 * n_side}" z="{n_side}"/><size value="1"/></light>']
+    cam = (f'<camera><position x="{0.2 * n_side}" y="{-1.1 * n_side}" z="{0.7 * n_side}"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/>'
+           '<fov value="40"/><width value="288"/><height value="176"/></camera>')
+    (tmp_path / "grid.xml").write_text("<xml><scene>" + "".join(body + mats + lights) + "</scene>" + cam + "</xml>")
+    return str(tmp_path / "grid.xml")
+
+
+@pytest.mark.parametrize("n_side", [14, 40])
+def test_many_instances_of_one_mesh(gpu_ctx, tmp_path, n_side):
+    """198 and 1602 scene nodes that share one BVH: the scan goes by groups of nodes (2 and 16 per mask bit).  Plain
+    kernel, counted kernel (full scan, checks every box hit against the group mask) and oracle must agree bit for bit."""
+    s = crt.Scene.load_xml(_instance_grid_xml(tmp_path, n_side), str(tmp_path))
+    assert s.desc().node_count == n_side * n_side + 2 and s.desc().mesh_count == 1
+    flat = str(tmp_path / "grid.crtscene")
+    s.save_file(flat)
+    o = orc.OracleScene(flat)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, 2)
+    acc = gpu_ctx.read_accumulators()
+    ref, cnt = o.render(0, 2, count=True)
+    for k, n in enumerate(("results", "normals", "albedos")):
+        assert same(acc[k], ref[k]), n
+    st = gpu_ctx.stats()
+    assert (st["closest_rays"], st["shadow_rays"]) == (cnt["closest_rays"], cnt["shadow_rays"])
+    gpu_ctx.clear()
+    gpu_ctx.render_pass_counted(0, 2)
+    assert same(gpu_ctx.read_accumulators()[0], ref[0])
+    chk = gpu_ctx.scan_check()
+    assert chk["checks"] > 0 and chk["violations"] == 0
+    full = gpu_ctx.stats(); full.pop("texel_quads"); cnt.pop("texel_quads")
+    assert full == cnt
 
