@@ -557,11 +557,12 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
     S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), 8, 1, 64);
     S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
-    S.slots = crt::knob_value(getenv("CRT_SLOTS"), 96 * S.trav_waves < kQueueSize ? 96 * S.trav_waves : kQueueSize, 64, kQueueSize);
+    S.slots = crt::knob_value(getenv("CRT_SLOTS"), 96 * S.trav_waves < kMaxSlots ? 96 * S.trav_waves : kMaxSlots, 64, kMaxSlots);
     S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
     S.serve_low_water = crt::knob_value(getenv("CRT_SERVE_LOW_WATER"), 64, 0, kQueueSize);
     S.serve_patience = crt::knob_value(getenv("CRT_SERVE_PATIENCE"), 64, 0, 1u << 20);
     S.serve_priority = crt::knob_value(getenv("CRT_SERVE_PRIORITY"), 1, 0, 1);
+    S.pair_below = crt::knob_value(getenv("CRT_PAIR_BELOW"), 0, 0, 1u << 20);
     S.watchdog_ticks = 100000000ull * crt::knob_value(getenv("CRT_WATCHDOG_SECONDS"), 30, 1, 3600);
     ctx->interleave = crt::knob_value(getenv("CRT_TILE_INTERLEAVE"), 0, 0, 1) != 0;
     { const char* e = getenv("CRT_NO_BALANCE"); ctx->no_balance = e && atoi(e) != 0; }
@@ -587,7 +588,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // two LDS arrays (node reference, entry distance) of stack_entries words per traversal thread
     const uint32_t trav_threads = S.trav_waves * 64;
     ctx->lds_bytes = (size_t)S.stack_entries * trav_threads * 4 * 2;
-    if (ctx->lds_bytes > 140 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");
+    if (ctx->lds_bytes > 126 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");      // 160 KiB less the queues and counters of the block
     for (int variant = 0; variant < 3; variant++)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_variant(ctx, variant == 1, variant == 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, trace_variant(ctx, false, false), CRT_BLOCK, ctx->lds_bytes));

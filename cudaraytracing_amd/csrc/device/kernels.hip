@@ -372,7 +372,7 @@ enum : uint32_t { H_NONE = 0, H_SPHERE = 1, H_PLANE = 2, H_MESH = 3 };
 // why a slot is in the shading queue
 enum : uint32_t { PK_NEW_PATH = 0, PK_CLOSEST_DONE = 1, PK_SHADOW_CLEAR = 2, PK_SHADOW_BLOCKED = 3, PK_FETCH = 4 };
 // what a shading turn decided for a slot
-enum : uint32_t { R_NONE = 0, R_RAY = 1, R_REFETCH = 2, R_RETIRE = 3 };
+enum : uint32_t { R_NONE = 0, R_RAY = 1, R_REFETCH = 2, R_RETIRE = 3, R_TWO_RAYS = 4 };
 constexpr uint32_t kPendExit = 0x20000000u;     // NODE: leave the mesh of node `entered` first
 
 struct Lane {
@@ -419,8 +419,17 @@ struct Lane {
 // slot numbers in LDS; an entry carries the lap number of its position, so a consumer that has claimed a position
 // knows when the producer's write has landed without a second counter.
 constexpr uint32_t kQueueLog = 11, kQueueSize = 1u << kQueueLog;      // ring positions; slots per block <= kQueueSize
-constexpr uint32_t kSlotWords = 64;
-constexpr uint32_t kRecRay = 0, kRecHit = 16, kRecPath = 32;
+constexpr uint32_t kSlotWords = 80;
+constexpr uint32_t kRecRay = 0, kRecHit = 16, kRecPath = 32, kRecShadowEnd = 60, kRecRay2 = 64;
+// A slot may have two queries under way at once: the shadow query of a light sample and the closest-hit query of the
+// next path segment do not depend on each other (the reference runs them one after the other, trace.cu:137-156).
+// The shadow query of such a pair is read from RAY2 and announced in the ray queue as slot | kSecondQuery, its
+// result goes to word kRecShadowEnd; whichever of the two ends last queues the slot for shading (join_bits).
+constexpr uint32_t kMaxSlots = kQueueSize, kSecondQuery = kMaxSlots;
+constexpr uint32_t kRayQueueLog = kQueueLog + 1, kRayQueueSize = 1u << kRayQueueLog;      // ring of ray queries: up to two per slot
+constexpr uint32_t kLanePaired = 0x80000000u;        // in Lane::slot: the query is one of a pair
+constexpr uint32_t kPkPaired = 0x100u;               // in the HIT record's first word, beside PK_CLOSEST_DONE: a shadow query ran beside this one
+static_assert(kRecRay2 + 16 <= kSlotWords && kRecShadowEnd >= kRecPath + 28 && kRecShadowEnd < kRecRay2, "slot record layout");
 constexpr uint32_t kMaxWaves = 16;
 
 struct BlockCtl {
@@ -430,6 +439,7 @@ struct BlockCtl {
     uint32_t ray_head, ray_tail;        // slots whose next query waits for a traversal lane
     uint32_t live;                      // slots that still have a pixel or may get one
     uint32_t abort;                     // a wave gave up waiting (a protocol error): every wave leaves
+    uint32_t dry;                       // the global pixel queue has nothing more for this block
 };
 
 DEV uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -437,7 +447,9 @@ DEV void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_REL
 
 // Every lane with `want` appends its slot.  The caller has made the slot's record visible to the block
 // (release fence) before the call.
+template <uint32_t kLog = kQueueLog>
 DEV void queue_push(uint32_t* tail, uint32_t* ring, bool want, uint32_t slot) {
+    constexpr uint32_t kSize = 1u << kLog;
     const unsigned long long m = __ballot(want);
     if (m == 0) return;
     uint32_t base = 0;
@@ -445,15 +457,17 @@ DEV void queue_push(uint32_t* tail, uint32_t* ring, bool want, uint32_t slot) {
     base = __shfl(base, __ffsll((long long)m) - 1, 64);
     if (want) {
         const uint32_t idx = base + lane_rank(m);
-        lds_st(&ring[idx & (kQueueSize - 1u)], (((idx >> kQueueLog) + 1u) << kQueueLog) | slot);
+        lds_st(&ring[idx & (kSize - 1u)], (((idx >> kLog) + 1u) << kLog) | slot);
     }
 }
 
 // The lanes with `want` claim up to that many entries, but none unless at least min_take are there; a lane that
 // got one returns true and its slot.  One compare-and-swap per wave; when another wave wins it the call
 // takes nothing and the caller comes back later.
+template <uint32_t kLog = kQueueLog>
 DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const uint32_t* ring, bool want, uint32_t min_take, uint32_t slot_limit,
                    uint32_t& slot, uint32_t* abort_flag) {
+    constexpr uint32_t kSize = 1u << kLog;
     const unsigned long long m = __ballot(want);
     if (m == 0) return false;
     const uint32_t nw = (uint32_t)__popcll(m);
@@ -462,7 +476,7 @@ DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const uint32_t* ring, b
         h = lds_ld(head);
         const uint32_t avail = lds_ld(tail) - h;
         k = avail < nw ? avail : nw;
-        if (k < min_take || avail > kQueueSize) k = 0;
+        if (k < min_take || avail > kSize) k = 0;
         if (k && atomicCAS(head, h, h + k) != h) k = 0;
     }
     const int leader = __ffsll((long long)m) - 1;
@@ -472,15 +486,15 @@ DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const uint32_t* ring, b
     const bool got = want && r < k;
     if (got) {
         const uint32_t idx = h + r;
-        const uint32_t tag = ((idx >> kQueueLog) + 1u) & ((1u << (32 - kQueueLog)) - 1u);
-        uint32_t e = lds_ld(&ring[idx & (kQueueSize - 1u)]), spins = 0;
+        const uint32_t tag = ((idx >> kLog) + 1u) & ((1u << (32 - kLog)) - 1u);
+        uint32_t e = lds_ld(&ring[idx & (kSize - 1u)]), spins = 0;
         // the producer reserved this position before the count said so; its write is a few instructions away
-        while ((e >> kQueueLog) != tag) {
+        while ((e >> kLog) != tag) {
             if (++spins > (1u << 22)) { lds_st(abort_flag, 1u); break; }
             __builtin_amdgcn_s_sleep(1);
-            e = lds_ld(&ring[idx & (kQueueSize - 1u)]);
+            e = lds_ld(&ring[idx & (kSize - 1u)]);
         }
-        slot = e & (kQueueSize - 1u);
+        slot = e & (kSize - 1u);
         if (slot >= slot_limit) slot = slot_limit - 1u;      // only after an abort: stay inside the block's records
     }
     return got;
@@ -501,7 +515,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                                                              float* __restrict__ out_t, uint32_t* slot_mem) {
     extern __shared__ uint32_t lds[];
     __shared__ BlockCtl ctl;
-    __shared__ uint32_t shade_ring[2][kQueueSize], ray_ring[kQueueSize];
+    __shared__ uint32_t shade_ring[2][kQueueSize], ray_ring[kRayQueueSize];
+    __shared__ uint32_t join_bits[kMaxSlots / 32];      // bit = slot: one query of the slot's pair has ended
     __shared__ unsigned long long sect_clock[kMaxWaves], path_sections[kMaxWaves * 8], wave_clock[kMaxWaves * 2];      // counted build only
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6;
@@ -512,13 +527,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
 
     // ---- block set-up: every slot starts in the shading queue asking for a pixel
     if (kCount) for (uint32_t i = tid; i < kMaxWaves * 8; i += CRT_BLOCK) path_sections[i] = 0;
+    for (uint32_t i = tid; i < kRayQueueSize; i += CRT_BLOCK) ray_ring[i] = 0;
     for (uint32_t i = tid; i < kQueueSize; i += CRT_BLOCK) {
-        ray_ring[i] = 0;
         shade_ring[0][i] = 0;
         shade_ring[1][i] = i < n_slots ? ((1u << kQueueLog) | i) : 0u;
     }
     for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
-    if (tid == 0) { ctl.shade_head[0] = 0; ctl.shade_tail[0] = 0; ctl.shade_head[1] = 0; ctl.shade_tail[1] = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; }
+    if (tid < kMaxSlots / 32) join_bits[tid] = 0;
+    if (tid == 0) { ctl.shade_head[0] = 0; ctl.shade_tail[0] = 0; ctl.shade_head[1] = 0; ctl.shade_tail[1] = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; ctl.dry = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -569,12 +585,13 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         Lane L = {};
         uint32_t state = S_IDLE;
 
+        // (slot * threads as a 24-bit product: the full 32-bit multiply issues at a quarter of the rate)
         auto stack_put = [&](uint32_t slot, uint32_t ref, float t) {
-            if (!kDeep || slot < lds_entries) { stack_ref[slot * trav_threads + tid] = ref; stack_t[slot * trav_threads + tid] = t; }
+            if (!kDeep || slot < lds_entries) { stack_ref[__umul24(slot, trav_threads) + tid] = ref; stack_t[__umul24(slot, trav_threads) + tid] = t; }
             else { my_overflow[(size_t)(2 * (slot - lds_entries)) * overflow_stride] = ref; my_overflow[(size_t)(2 * (slot - lds_entries) + 1) * overflow_stride] = __float_as_uint(t); }
         };
         auto stack_get = [&](uint32_t slot, uint32_t& ref, float& t) {
-            if (!kDeep || slot < lds_entries) { ref = stack_ref[slot * trav_threads + tid]; t = stack_t[slot * trav_threads + tid]; }
+            if (!kDeep || slot < lds_entries) { ref = stack_ref[__umul24(slot, trav_threads) + tid]; t = stack_t[__umul24(slot, trav_threads) + tid]; }
             else { ref = my_overflow[(size_t)(2 * (slot - lds_entries)) * overflow_stride]; t = __uint_as_float(my_overflow[(size_t)(2 * (slot - lds_entries) + 1) * overflow_stride]); }
         };
 
@@ -868,33 +885,47 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // those belong to
         auto op_exchange = [&]() {
             const bool post = state == S_POST;
+            const uint32_t my_slot = L.slot & (kMaxSlots - 1u);
+            const bool paired = (L.slot & kLanePaired) != 0;
             if (post) {
-                uint32_t* rec = slot_rec(L.slot) + kRecHit;
+                uint32_t* rec = slot_rec(my_slot) + kRecHit;
                 if (L.pk == PK_CLOSEST_DONE) {
                     uint4* r4 = reinterpret_cast<uint4*>(rec);
                     const f3 qp = L.qpos(), qd = L.qdir();
-                    r4[0] = uint4{L.pk, __float_as_uint(L.hz), L.h_kind | (L.h_front ? 4u : 0u) | (L.h_node << 3), L.h_c};
-                    r4[1] = uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), __float_as_uint(L.h_a)};
-                    r4[2] = uint4{__float_as_uint(qp.x), __float_as_uint(qp.y), __float_as_uint(qp.z), __float_as_uint(L.h_b)};
                     // last word: 0, or the node whose space the ray (and a hit found in it) is still in: node + 1, bit 31 = hit found there
                     const uint32_t inside = L.pend == kPendExit ? ((L.entered + 1u) | (L.mesh_hit ? 0x80000000u : 0u)) : 0u;
+                    r4[0] = uint4{L.pk | (paired ? kPkPaired : 0u), __float_as_uint(L.hz), L.h_kind | (L.h_front ? 4u : 0u) | (L.h_node << 3), L.h_c};
+                    r4[1] = uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), __float_as_uint(L.h_a)};
+                    r4[2] = uint4{__float_as_uint(qp.x), __float_as_uint(qp.y), __float_as_uint(qp.z), __float_as_uint(L.h_b)};
                     r4[3] = uint4{__float_as_uint(qd.x), __float_as_uint(qd.y), __float_as_uint(qd.z), inside};
+                } else if (paired) {
+                    slot_rec(my_slot)[kRecShadowEnd] = L.pk;
                 } else {
                     rec[0] = L.pk;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            queue_push(&ctl.shade_tail[0], shade_ring[0], post && L.pk == PK_CLOSEST_DONE, L.slot);
-            queue_push(&ctl.shade_tail[1], shade_ring[1], post && L.pk != PK_CLOSEST_DONE, L.slot);
+            // of a pair, the query that ends second hands the slot on (both results are in the record by then)
+            bool hand_on = post;
+            if (post && paired) {
+                const uint32_t bit = 1u << (my_slot & 31u);
+                hand_on = (__hip_atomic_fetch_xor(&join_bits[my_slot >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) != 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            queue_push(&ctl.shade_tail[0], shade_ring[0], hand_on && (paired || L.pk == PK_CLOSEST_DONE), my_slot);
+            queue_push(&ctl.shade_tail[1], shade_ring[1], hand_on && !paired && L.pk != PK_CLOSEST_DONE, my_slot);
             if (post) state = S_IDLE;
             uint32_t slot = 0;
-            const bool got = queue_pop(&ctl.ray_head, &ctl.ray_tail, ray_ring, state == S_IDLE, 1u, n_slots, slot, &ctl.abort);
+            const bool got = queue_pop<kRayQueueLog>(&ctl.ray_head, &ctl.ray_tail, ray_ring, state == S_IDLE, 1u, kRayQueueSize, slot, &ctl.abort);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (kCount) { const uint32_t n_got = (uint32_t)__popcll(__ballot(got)); if ((tid & 63u) == 0) tally.cycles[5] += n_got; }
             if (got) {
-                const uint4* r4 = reinterpret_cast<const uint4*>(slot_rec(slot) + kRecRay);
+                const uint32_t second = slot & kSecondQuery;
+                slot &= kMaxSlots - 1u;
+                if (slot >= n_slots) slot = n_slots - 1u;      // only after an abort: stay inside the block's records
+                const uint4* r4 = reinterpret_cast<const uint4*>(slot_rec(slot) + (second ? kRecRay2 : kRecRay));
                 const uint4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
-                L.slot = slot;
+                L.slot = slot | ((b.w & 2u) ? kLanePaired : 0u);
                 L.pdx = f2{__uint_as_float(a.x), __uint_as_float(b.x)};
                 L.pdy = f2{__uint_as_float(a.y), __uint_as_float(b.y)};
                 L.pdz = f2{__uint_as_float(a.z), __uint_as_float(b.z)};
@@ -1006,7 +1037,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             constexpr bool kClosest = decltype(kind)::value;
             uint32_t result = R_NONE;
             uint32_t* const rec = slot_rec(have ? slot : 0u);
+            // Two queries of a pixel at once shorten its chain of queries, at the price of shading turns that are less
+            // uniform (the second query's set-up runs only for the lanes that have one).  While the block still takes
+            // new pixels the kernel is bound by throughput and the trade does not pay; once the pixel queue is dry the
+            // frame lasts as long as the longest chain, and it does.  (pair_below: also while few queries are ready.)
+            const bool pair_now = kClosest && (lds_ld(&ctl.dry) != 0 || lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) < S.pair_below);
             uint32_t pk = have ? rec[kRecHit] : (uint32_t)PK_NEW_PATH;
+            const bool was_paired = kClosest && (pk & kPkPaired) != 0;
+            pk &= ~kPkPaired;
             Rng rng = {};
             uint32_t pI = 0, tile = 0, cost = 0, segments = 0;
             int sample = 0;
@@ -1027,6 +1065,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                         base = __shfl(base, __ffsll((long long)mask) - 1, 64);
                         if (base + cnt >= P.total_items) {      // uniform: the queue has run dry
                             queue_empty = true;
+                            lds_st(&ctl.dry, 1u);
                             if (kCount && lane_rank(__ballot(true)) == 0 && wave_clock[wave * 2 + 1] == 0) wave_clock[wave * 2 + 1] = __builtin_amdgcn_s_memtime();
                         }
                         if (need) {
@@ -1075,6 +1114,12 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 next_dir = mk3(__uint_as_float(p4.x), __uint_as_float(p4.y), __uint_as_float(p4.z));
                 hpos = mk3(__uint_as_float(p5.w), __uint_as_float(path4[6].x), __uint_as_float(path4[6].y));
             } else if (kClosest) {
+                // the shadow query that ran beside this closest-hit query: its light sample comes first (trace.cu:137-143)
+                if (was_paired) {
+                    const uint4 p5 = path4[5];
+                    if (rec[kRecShadowEnd] == PK_SHADOW_CLEAR && (rec[kRecPath + 19] & 1u))
+                        acc_add(acc_target, mk3(__uint_as_float(p5.x), __uint_as_float(p5.y), __uint_as_float(p5.z)));
+                }
                 const uint4* hit4 = reinterpret_cast<const uint4*>(rec + kRecHit);
                 const uint4 h0 = hit4[0], h1 = hit4[1], h2 = hit4[2], h3 = hit4[3];
                 hz = __uint_as_float(h0.y);
@@ -1326,7 +1371,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     }
                     if (want_shadow) {
                         // parked until the shadow query comes back: continuation direction, light sample, hit position
-                        path4[4] = uint4{__float_as_uint(next_dir.x), __float_as_uint(next_dir.y), __float_as_uint(next_dir.z), (nee_valid ? 1u : 0u) | (alive ? 2u : 0u)};
+                        // (flag 4: the continuation is under way beside the shadow query)
+                        path4[4] = uint4{__float_as_uint(next_dir.x), __float_as_uint(next_dir.y), __float_as_uint(next_dir.z), (nee_valid ? 1u : 0u) | (alive ? (pair_now ? 6u : 2u) : 0u)};
                         path4[5] = uint4{__float_as_uint(nee.x), __float_as_uint(nee.y), __float_as_uint(nee.z), __float_as_uint(hpos.x)};
                         rec[kRecPath + 24] = __float_as_uint(hpos.y); rec[kRecPath + 25] = __float_as_uint(hpos.z);
                     }
@@ -1338,8 +1384,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             f3 rpos, rdir;
             float rlimit;
             bool rshadow;
-            if (want_shadow) {
-                tally.shadow_rays++;
+            // A light sample whose path goes on: the shadow query and the next segment's closest-hit query may start
+            // together (pair_now, the same for the whole turn).
+            const bool two = want_shadow && alive && pair_now;
+            if (want_shadow) tally.shadow_rays++;
+            if (want_shadow && !two) {
                 rpos = spos; rdir = sdir; rlimit = sdist; rshadow = true;
                 result = R_RAY;
             } else {
@@ -1365,7 +1414,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     rlimit = CRT_BIGFLOAT;
                     rshadow = false;
                     tally.closest_rays++;
-                    result = R_RAY;
+                    result = two ? R_TWO_RAYS : R_RAY;
                 } else {
                     rlimit = 0; rshadow = false;
                     result = R_REFETCH;
@@ -1374,25 +1423,29 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             path4[0] = uint4{rng.d, rng.v0, rng.v1, rng.v2};
             path4[1] = uint4{rng.v3, rng.v4, __float_as_uint(contrib.x), __float_as_uint(contrib.y)};
             path4[2] = uint4{__float_as_uint(contrib.z), __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
-            path4[3] = uint4{(uint32_t)sample, segments, cost + 1u, pI};
+            path4[3] = uint4{(uint32_t)sample, segments, cost + (two ? 2u : 1u), pI};
             if (fresh) rec[kRecPath + 26] = tile;
-            if (result == R_RAY) {
-                // one pass over the node boxes for the query the slot is about to start
+            // a query's record: the ray, and one pass over the node boxes for the scan's candidate mask
+            auto write_query = [&](uint32_t* dst, f3 qpos_, f3 qdir_, float qlimit, bool qshadow) {
                 NodeMask mask = {~0ull, ~0ull};
                 uint32_t node = 0;
                 if (S.scan_mask) {
-                    mask = grouped ? scan_candidates(S, S.group_pairs, S.group_count, rpos, rdir, rlimit, false)
-                                   : scan_candidates(S, pairs, node_count, rpos, rdir, rlimit, rshadow);
+                    mask = grouped ? scan_candidates(S, S.group_pairs, S.group_count, qpos_, qdir_, qlimit, false)
+                                   : scan_candidates(S, pairs, node_count, qpos_, qdir_, qlimit, qshadow);
                     const uint32_t first = mask.lo ? (uint32_t)__ffsll((long long)mask.lo) - 1u : (mask.hi ? 63u + (uint32_t)__ffsll((long long)mask.hi) : 0xffffffffu);
                     if (by_mask) node = first < node_count ? first : node_count;
                     if (by_group) node = first < S.group_count ? first << group_shift : node_count;
                 }
-                const f3 rinv = recip3(rdir);
-                uint4* ray4 = reinterpret_cast<uint4*>(rec + kRecRay);
-                ray4[0] = uint4{__float_as_uint(rpos.x), __float_as_uint(rpos.y), __float_as_uint(rpos.z), __float_as_uint(rlimit)};
-                ray4[1] = uint4{__float_as_uint(rdir.x), __float_as_uint(rdir.y), __float_as_uint(rdir.z), rshadow ? 1u : 0u};
+                const f3 rinv = recip3(qdir_);
+                uint4* ray4 = reinterpret_cast<uint4*>(dst);
+                ray4[0] = uint4{__float_as_uint(qpos_.x), __float_as_uint(qpos_.y), __float_as_uint(qpos_.z), __float_as_uint(qlimit)};
+                ray4[1] = uint4{__float_as_uint(qdir_.x), __float_as_uint(qdir_.y), __float_as_uint(qdir_.z), (qshadow ? 1u : 0u) | (two ? 2u : 0u)};
                 ray4[2] = uint4{__float_as_uint(rinv.x), __float_as_uint(rinv.y), __float_as_uint(rinv.z), node};
                 ray4[3] = uint4{(uint32_t)mask.lo, (uint32_t)(mask.lo >> 32), (uint32_t)mask.hi, (uint32_t)(mask.hi >> 32)};
+            };
+            if (result == R_RAY || result == R_TWO_RAYS) {
+                write_query(rec + kRecRay, rpos, rdir, rlimit, rshadow);
+                if (kClosest && two) write_query(rec + kRecRay2, spos, sdir, sdist, true);
             } else {
                 rec[kRecHit] = PK_FETCH;
             }
@@ -1427,7 +1480,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.turns[3]++; tally.lanes[3] += have; }
             const uint32_t result = which == 0 ? serve(std::true_type{}, have, slot) : serve(std::false_type{}, have, slot);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            queue_push(&ctl.ray_tail, ray_ring, result == R_RAY, slot);
+            queue_push<kRayQueueLog>(&ctl.ray_tail, ray_ring, result == R_RAY || result == R_TWO_RAYS, slot);
+            queue_push<kRayQueueLog>(&ctl.ray_tail, ray_ring, result == R_TWO_RAYS, slot | kSecondQuery);
             queue_push(&ctl.shade_tail[1], shade_ring[1], result == R_REFETCH, slot);
             const unsigned long long retired = __ballot(result == R_RETIRE);
             if (retired != 0 && lane_rank(__ballot(true)) == 0) atomicSub(&ctl.live, (uint32_t)__popcll(retired));

@@ -8,7 +8,7 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 s = crt.Scene.load_file(os.path.join(ROOT, "tests/golden/scenes/final_frame0042.crtscene")); s.set_resolution(1920, 1080)
 ctx = crt.Context(0); ctx.upload(s)
 base = None
-for parts in (1, 2, 4, 8):
+for parts in [int(x) for x in os.environ.get("PROBE_PARTS", "1,2,4,8").split(",")]:
     worst = 0.0
     for part in range(parts):
         ctx.set_partition(part, parts, 8)
