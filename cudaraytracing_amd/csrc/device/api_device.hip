@@ -555,7 +555,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // triangle scene, prefers a higher box threshold).  Environment overrides outside the stated range are ignored.
     S.sched_box_min = crt::knob_value(getenv("CRT_SCHED_BOX_MIN"), 20, 1, 64);
     S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
-    S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), 8, 1, 64);
+    S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), 12, 1, 64);
     S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
     S.slots = crt::knob_value(getenv("CRT_SLOTS"), 96 * S.trav_waves < kMaxSlots ? 96 * S.trav_waves : kMaxSlots, 64, kMaxSlots);
     S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
