@@ -562,6 +562,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.serve_low_water = crt::knob_value(getenv("CRT_SERVE_LOW_WATER"), 64, 0, kQueueSize);
     S.serve_patience = crt::knob_value(getenv("CRT_SERVE_PATIENCE"), 64, 0, 1u << 20);
     S.serve_priority = crt::knob_value(getenv("CRT_SERVE_PRIORITY"), 1, 0, 1);
+    S.pair_live = crt::knob_value(getenv("CRT_PAIR_LIVE"), S.trav_waves * 80, 0, 1u << 20);
     S.pair_below = crt::knob_value(getenv("CRT_PAIR_BELOW"), 0, 0, 1u << 20);
     S.watchdog_ticks = 100000000ull * crt::knob_value(getenv("CRT_WATCHDOG_SECONDS"), 30, 1, 3600);
     ctx->interleave = crt::knob_value(getenv("CRT_TILE_INTERLEAVE"), 0, 0, 1) != 0;

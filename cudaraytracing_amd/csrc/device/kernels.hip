@@ -439,7 +439,6 @@ struct BlockCtl {
     uint32_t ray_head, ray_tail;        // slots whose next query waits for a traversal lane
     uint32_t live;                      // slots that still have a pixel or may get one
     uint32_t abort;                     // a wave gave up waiting (a protocol error): every wave leaves
-    uint32_t dry;                       // the global pixel queue has nothing more for this block
 };
 
 DEV uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -534,7 +533,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     }
     for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
     if (tid < kMaxSlots / 32) join_bits[tid] = 0;
-    if (tid == 0) { ctl.shade_head[0] = 0; ctl.shade_tail[0] = 0; ctl.shade_head[1] = 0; ctl.shade_tail[1] = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; ctl.dry = 0; }
+    if (tid == 0) { ctl.shade_head[0] = 0; ctl.shade_tail[0] = 0; ctl.shade_head[1] = 0; ctl.shade_tail[1] = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1038,10 +1037,12 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             uint32_t result = R_NONE;
             uint32_t* const rec = slot_rec(have ? slot : 0u);
             // Two queries of a pixel at once shorten its chain of queries, at the price of shading turns that are less
-            // uniform (the second query's set-up runs only for the lanes that have one).  While the block still takes
-            // new pixels the kernel is bound by throughput and the trade does not pay; once the pixel queue is dry the
-            // frame lasts as long as the longest chain, and it does.  (pair_below: also while few queries are ready.)
-            const bool pair_now = kClosest && (lds_ld(&ctl.dry) != 0 || lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) < S.pair_below);
+            // uniform (the second query's set-up runs only for the lanes that have one).  While the block has pixels
+            // enough to keep its traversal lanes busy the kernel is bound by throughput and the trade does not pay;
+            // once slots have retired (no pixels left to take: the end of a frame, or a small share of one) and fewer
+            // than pair_live of them are left, the frame lasts as long as the longest chain, and it does.
+            // (pair_below: pair also while few queries are ready.)
+            const bool pair_now = kClosest && (lds_ld(&ctl.live) < S.pair_live || lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) < S.pair_below);
             uint32_t pk = have ? rec[kRecHit] : (uint32_t)PK_NEW_PATH;
             const bool was_paired = kClosest && (pk & kPkPaired) != 0;
             pk &= ~kPkPaired;
@@ -1065,7 +1066,6 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                         base = __shfl(base, __ffsll((long long)mask) - 1, 64);
                         if (base + cnt >= P.total_items) {      // uniform: the queue has run dry
                             queue_empty = true;
-                            lds_st(&ctl.dry, 1u);
                             if (kCount && lane_rank(__ballot(true)) == 0 && wave_clock[wave * 2 + 1] == 0) wave_clock[wave * 2 + 1] = __builtin_amdgcn_s_memtime();
                         }
                         if (need) {

@@ -7,6 +7,9 @@ import cudaraytracing_amd as crt
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 s = crt.Scene.load_file(os.path.join(ROOT, "tests/golden/scenes/final_frame0042.crtscene")); s.set_resolution(1920, 1080)
 ctx = crt.Context(0); ctx.upload(s)
+if os.environ.get("PROBE_PART"):      # "part,parts": one rank's share of the frame
+    part, parts = (int(v) for v in os.environ["PROBE_PART"].split(","))
+    ctx.set_partition(part, parts, 8)
 ctx.render_pass(0, spp); ctx.clear()      # first pass measures the tile costs the counted pass is scheduled by
 ctx.render_pass_counted(0, spp)
 print("counted kernel ms", ctx.last_kernel_ms())
