@@ -26,6 +26,10 @@
 //     ray of a new path, the next pixel of a finished slot) for up to 64 slots
 //     at a time, whichever lanes finished them, in turns that are all of one
 //     kind (closest-hit query ended / shadow query ended or pixel needed).
+// When a block runs short of pixels, a pixel's shadow query and the closest-hit
+// query of its next path segment run side by side (they are independent; the
+// results are joined in the reference's order), which shortens the chain of
+// dependent queries that bounds the end of a frame.
 // So both kinds of wave work with their lanes full of the same kind of work,
 // traversal state is the only thing in a traversal lane's registers, and the
 // kernel spills nothing.  The order of operations of any one pixel is exactly
