@@ -599,3 +599,27 @@ def test_many_instances_of_one_mesh(gpu_ctx, tmp_path, n_side):
     full = gpu_ctx.stats(); full.pop("texel_quads"); cnt.pop("texel_quads")
     assert full == cnt
 
+
+@pytest.mark.parametrize("name,w,h,spp", [("final_frame0042", 640, 360, 8), ("proj5_glasspot", 480, 270, 6), ("proj7_checkerboard", 480, 270, 8)])
+def test_paired_queries_change_nothing(gpu_ctx, monkeypatch, name, w, h, spp):
+    """A pixel's shadow query and the closest-hit query of its next path segment may run side by side or one after the
+    other; the kernel chooses by how many pixels its blocks have left.  Forced either way, accumulators and ray counts
+    must equal the oracle's bit for bit (at this size the default mixes both: the blocks run out of pixels early)."""
+    s, o = load_both(name, w, h)
+    ref, cnt = o.render(0, spp, count=True)
+    for setting in ("0", "100000", None):
+        if setting is None:
+            monkeypatch.delenv("CRT_PAIR_LIVE", raising=False)
+        else:
+            monkeypatch.setenv("CRT_PAIR_LIVE", setting)      # never / always
+        gpu_ctx.upload(s)
+        gpu_ctx.clear()
+        gpu_ctx.render_pass(0, spp)
+        acc = gpu_ctx.read_accumulators()
+        for k, n in enumerate(("results", "normals", "albedos")):
+            assert same(acc[k], ref[k]), (setting, n)
+        st = gpu_ctx.stats()
+        assert (st["closest_rays"], st["shadow_rays"]) == (cnt["closest_rays"], cnt["shadow_rays"]), setting
+    monkeypatch.delenv("CRT_PAIR_LIVE", raising=False)
+    gpu_ctx.upload(s)
+
