@@ -551,18 +551,20 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         // profiling only: the counted build then scans by the mask too (its node counters no longer match the reference's)
         if (const char* e = getenv("CRT_COUNTED_BY_MASK")) if (atoi(e) != 0 && S.scan_mask) S.scan_mask = 3;
     }
-    // Scheduler and block-shape parameters (defaults measured on the benchmark frame; a deep BVH, the ten-million-
-    // triangle scene, prefers a higher box threshold).  Environment overrides outside the stated range are ignored.
-    S.sched_box_min = crt::knob_value(getenv("CRT_SCHED_BOX_MIN"), 20, 1, 64);
+    // Scheduler and block-shape parameters: defaults measured on the benchmark frame (cache resident, bound by
+    // instruction issue) and, for a BVH deeper than the LDS stack, on the ten-million-triangle scene (bound by memory
+    // latency: longer box bursts, later exchanges, and two queries per pixel in flight whenever there are two).
+    // Environment overrides outside the stated range are ignored.
+    S.sched_box_min = crt::knob_value(getenv("CRT_SCHED_BOX_MIN"), ctx->deep ? 32 : 20, 1, 64);
     S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
-    S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), 12, 1, 64);
+    S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), ctx->deep ? 16 : 12, 1, 64);
     S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
     S.slots = crt::knob_value(getenv("CRT_SLOTS"), 96 * S.trav_waves < kMaxSlots ? 96 * S.trav_waves : kMaxSlots, 64, kMaxSlots);
     S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
     S.serve_low_water = crt::knob_value(getenv("CRT_SERVE_LOW_WATER"), 64, 0, kQueueSize);
     S.serve_patience = crt::knob_value(getenv("CRT_SERVE_PATIENCE"), 64, 0, 1u << 20);
     S.serve_priority = crt::knob_value(getenv("CRT_SERVE_PRIORITY"), 1, 0, 1);
-    S.pair_live = crt::knob_value(getenv("CRT_PAIR_LIVE"), S.trav_waves * 80, 0, 1u << 20);
+    S.pair_live = crt::knob_value(getenv("CRT_PAIR_LIVE"), ctx->deep ? (1u << 20) : S.trav_waves * 80, 0, 1u << 20);
     S.pair_below = crt::knob_value(getenv("CRT_PAIR_BELOW"), 0, 0, 1u << 20);
     S.watchdog_ticks = 100000000ull * crt::knob_value(getenv("CRT_WATCHDOG_SECONDS"), 30, 1, 3600);
     ctx->interleave = crt::knob_value(getenv("CRT_TILE_INTERLEAVE"), 0, 0, 1) != 0;

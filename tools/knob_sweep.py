@@ -9,7 +9,11 @@ import cudaraytracing_amd as crt
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 scene = os.environ.get("SWEEP_SCENE", "final_frame0042")
 w, h = (int(v) for v in os.environ.get("SWEEP_SIZE", "1920x1080").split("x"))
-s = crt.Scene.load_file(os.path.join(ROOT, f"tests/golden/scenes/{scene}.crtscene")); s.set_resolution(w, h)
+s = crt.Scene.load_file(os.path.join(ROOT, f"tests/golden/scenes/{scene}.crtscene"))
+if os.environ.get("SWEEP_COPIES"):      # the synthetic instanced scene: SWEEP_SCENE=proj5_box SWEEP_COPIES=1582 SWEEP_SIZE=3840x2160
+    s = s.make_instanced(0, int(os.environ["SWEEP_COPIES"]), 1, w, h)
+else:
+    s.set_resolution(w, h)
 KNOBS = ("SCHED_BOX_MIN", "SCHED_SPECIAL_MIN", "SCHED_EXCHANGE_MIN", "TRAV_WAVES", "SLOTS", "SERVE_BATCH_MIN", "SERVE_LOW_WATER", "SERVE_PATIENCE", "SERVE_PRIORITY", "TILE_INTERLEAVE", "NO_BALANCE", "PAIR_BELOW", "PAIR_LIVE")
 for spec in sys.argv[2:] or [""]:
     for k in KNOBS:
