@@ -474,14 +474,15 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cam_pos, cam.position, 12); S.dof = cam.dof; S.pixel_size = cam.pixel_size;
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
-    // LDS holds at most kLdsStackEntries stack entries per traversal lane (two blocks of 512 threads stay resident);
+    // LDS holds at most kLdsStackEntries stack entries per traversal lane (21 x 832 lanes x 8 bytes = 137 KiB);
     // deeper trees use the kernel variant whose stack overflows into the side buffer.  CRT_STACK_ENTRIES overrides the
     // number (tests: the same scene with the whole stack in LDS, or with almost all of it in the side buffer).
-    const uint32_t kLdsStackEntries = crt::knob_value(getenv("CRT_STACK_ENTRIES"), 19, 2, 66);
+    const uint32_t kLdsStackEntries = crt::knob_value(getenv("CRT_STACK_ENTRIES"), 21, 2, 66);
     const uint32_t stack_total = max_depth + 2;
     ctx->deep = stack_total > kLdsStackEntries;
     ctx->stack_overflow = ctx->deep ? stack_total - kLdsStackEntries : 0;
     S.stack_entries = ctx->deep ? kLdsStackEntries : stack_total;
+    S.stack_overflow = ctx->stack_overflow;
     {
         // Drift bound of the scan's candidate mask.  One round trip through node j maps p to fl(tm * fl(itm * p)): its
         // distance from p is at most |R p + r| (R = tm3 * itm3 - I, r = tm3 * t_itm + t_tm: the stored matrices are
@@ -591,7 +592,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // two LDS arrays (node reference, entry distance) of stack_entries words per traversal thread
     const uint32_t trav_threads = S.trav_waves * 64;
     ctx->lds_bytes = (size_t)S.stack_entries * trav_threads * 4 * 2;
-    if (ctx->lds_bytes > 126 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");      // 160 KiB less the queues and counters of the block
+    if (ctx->lds_bytes > 141 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");      // 160 KiB less the queues and counters of the block (18 KiB)
     for (int variant = 0; variant < 3; variant++)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_variant(ctx, variant == 1, variant == 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, trace_variant(ctx, false, false), CRT_BLOCK, ctx->lds_bytes));

@@ -112,6 +112,7 @@ struct DevScene {
     uint32_t node_count, light_count;
     int32_t env_texture;
     uint32_t stack_entries;          // LDS stack slots per lane (deeper entries overflow into the side buffer)
+    uint32_t stack_overflow;         // entries per lane beyond those, kept in device memory behind the slot records
     uint32_t sched_box_min;          // box steps run unconditionally while this many lanes of a wave want one
     uint32_t sched_special_min;      // a triangle / transform turn runs once this many lanes wait for it
     uint32_t sched_exchange_min;     // an exchange turn (post results, take new queries) runs once this many lanes want one

@@ -396,7 +396,8 @@ struct Lane {
     unsigned long long mask;        // scene nodes the scan still has to test (bit i = node i), when it runs by candidates
     unsigned long long mask_hi;     // the same for nodes 64..127 (scenes of more than 64 nodes)
     uint32_t cur;                   // BVH record to expand
-    uint32_t sp;                    // LDS stack height
+    uint32_t sp;                    // stack height
+    uint32_t lo, top;               // deep trees only: lowest stack index still in LDS, ring position of index sp
     uint32_t entered;               // scene node whose mesh is being traversed
     uint32_t pend;                  // LEAF: remaining leaf range; NODE: kPendExit when a mesh has to be left first
     bool shadow, mesh_hit;
@@ -447,11 +448,17 @@ struct BlockCtl {
 
 DEV uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Ring entries are 16 bits wide (LDS is what limits the traversal stack): the low kLog bits are the value, the bits
+// above them the lap number of the position, truncated.  A position always holds what the previous lap wrote there
+// until this lap's producer overwrites it, so the truncated lap number tells the two apart.
+typedef uint16_t ring_t;
+DEV uint32_t ring_ld(const ring_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void ring_st(ring_t* p, uint32_t v) { __hip_atomic_store(p, (ring_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Every lane with `want` appends its slot.  The caller has made the slot's record visible to the block
 // (release fence) before the call.
 template <uint32_t kLog = kQueueLog>
-DEV void queue_push(uint32_t* tail, uint32_t* ring, bool want, uint32_t slot) {
+DEV void queue_push(uint32_t* tail, ring_t* ring, bool want, uint32_t slot) {
     constexpr uint32_t kSize = 1u << kLog;
     const unsigned long long m = __ballot(want);
     if (m == 0) return;
@@ -460,7 +467,7 @@ DEV void queue_push(uint32_t* tail, uint32_t* ring, bool want, uint32_t slot) {
     base = __shfl(base, __ffsll((long long)m) - 1, 64);
     if (want) {
         const uint32_t idx = base + lane_rank(m);
-        lds_st(&ring[idx & (kSize - 1u)], (((idx >> kLog) + 1u) << kLog) | slot);
+        ring_st(&ring[idx & (kSize - 1u)], (((idx >> kLog) + 1u) << kLog) | slot);
     }
 }
 
@@ -468,7 +475,7 @@ DEV void queue_push(uint32_t* tail, uint32_t* ring, bool want, uint32_t slot) {
 // got one returns true and its slot.  One compare-and-swap per wave; when another wave wins it the call
 // takes nothing and the caller comes back later.
 template <uint32_t kLog = kQueueLog>
-DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const uint32_t* ring, bool want, uint32_t min_take, uint32_t slot_limit,
+DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const ring_t* ring, bool want, uint32_t min_take, uint32_t slot_limit,
                    uint32_t& slot, uint32_t* abort_flag) {
     constexpr uint32_t kSize = 1u << kLog;
     const unsigned long long m = __ballot(want);
@@ -489,13 +496,13 @@ DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const uint32_t* ring, b
     const bool got = want && r < k;
     if (got) {
         const uint32_t idx = h + r;
-        const uint32_t tag = ((idx >> kLog) + 1u) & ((1u << (32 - kLog)) - 1u);
-        uint32_t e = lds_ld(&ring[idx & (kSize - 1u)]), spins = 0;
+        const uint32_t tag = ((idx >> kLog) + 1u) & ((1u << (16 - kLog)) - 1u);
+        uint32_t e = ring_ld(&ring[idx & (kSize - 1u)]), spins = 0;
         // the producer reserved this position before the count said so; its write is a few instructions away
         while ((e >> kLog) != tag) {
             if (++spins > (1u << 22)) { lds_st(abort_flag, 1u); break; }
             __builtin_amdgcn_s_sleep(1);
-            e = lds_ld(&ring[idx & (kSize - 1u)]);
+            e = ring_ld(&ring[idx & (kSize - 1u)]);
         }
         slot = e & (kSize - 1u);
         if (slot >= slot_limit) slot = slot_limit - 1u;      // only after an abort: stay inside the block's records
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                                                              float* __restrict__ out_t, uint32_t* slot_mem) {
     extern __shared__ uint32_t lds[];
     __shared__ BlockCtl ctl;
-    __shared__ uint32_t shade_ring[2][kQueueSize], ray_ring[kRayQueueSize];
+    __shared__ ring_t shade_ring[2][kQueueSize], ray_ring[kRayQueueSize];
     __shared__ uint32_t join_bits[kMaxSlots / 32];      // bit = slot: one query of the slot's pair has ended
     __shared__ unsigned long long sect_clock[kMaxWaves], path_sections[kMaxWaves * 8], wave_clock[kMaxWaves * 2];      // counted build only
     const uint32_t tid = threadIdx.x;
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     for (uint32_t i = tid; i < kRayQueueSize; i += CRT_BLOCK) ray_ring[i] = 0;
     for (uint32_t i = tid; i < kQueueSize; i += CRT_BLOCK) {
         shade_ring[0][i] = 0;
-        shade_ring[1][i] = i < n_slots ? ((1u << kQueueLog) | i) : 0u;
+        shade_ring[1][i] = (ring_t)(i < n_slots ? ((1u << kQueueLog) | i) : 0u);
     }
     for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
     if (tid < kMaxSlots / 32) join_bits[tid] = 0;
@@ -582,20 +589,40 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * trav_threads);
         const uint32_t lds_entries = S.stack_entries;
         // overflow of the traversal stack (deep trees): behind the slot records, one column per traversal thread
-        uint32_t* const my_overflow = slot_mem + (size_t)gridDim.x * n_slots * kSlotWords + ((size_t)blockIdx.x * trav_threads + tid);
-        const size_t overflow_stride = (size_t)gridDim.x * trav_threads;
+        // (laid out [block][entry][thread], reference and distance of an entry side by side: one 8-byte access per lane)
+        uint2* const my_overflow = reinterpret_cast<uint2*>(slot_mem + (size_t)gridDim.x * n_slots * kSlotWords) +
+                                   ((size_t)blockIdx.x * S.stack_overflow * trav_threads + tid);
 
         Lane L = {};
         uint32_t state = S_IDLE;
 
-        // (slot * threads as a 24-bit product: the full 32-bit multiply issues at a quarter of the rate)
-        auto stack_put = [&](uint32_t slot, uint32_t ref, float t) {
-            if (!kDeep || slot < lds_entries) { stack_ref[__umul24(slot, trav_threads) + tid] = ref; stack_t[__umul24(slot, trav_threads) + tid] = t; }
-            else { my_overflow[(size_t)(2 * (slot - lds_entries)) * overflow_stride] = ref; my_overflow[(size_t)(2 * (slot - lds_entries) + 1) * overflow_stride] = __float_as_uint(t); }
+        // Push / pop.  (slot * threads as a 24-bit product: the full 32-bit multiply issues at a quarter of the rate.)
+        // kDeep: the tree is deeper than the LDS stack.  LDS then holds the TOP of the stack, as a ring of lds_entries
+        // positions: entries [L.lo, L.sp) live at position index % lds_entries (L.top is that position for L.sp), and a
+        // push into a full ring first moves the oldest entry, the one the new one is about to overwrite, to its place
+        // in device memory.  Pops meet memory only when a walk has come back below everything the ring holds.
+        auto stack_push = [&](uint32_t ref, float t, bool keep) {
+            if (!kDeep) {
+                // written even when it is not kept (the slot above the top, left unused): no branch around the write
+                stack_ref[__umul24(L.sp, trav_threads) + tid] = ref; stack_t[__umul24(L.sp, trav_threads) + tid] = t;
+                L.sp += keep ? 1u : 0u;
+            } else if (keep) {
+                const uint32_t at = __umul24(L.top, trav_threads) + tid;
+                if (L.sp - L.lo == lds_entries) {
+                    my_overflow[__umul24(L.lo, trav_threads)] = uint2{stack_ref[at], __float_as_uint(stack_t[at])};
+                    L.lo++;
+                }
+                stack_ref[at] = ref; stack_t[at] = t;
+                L.sp++;
+                L.top = L.top + 1u == lds_entries ? 0u : L.top + 1u;
+            }
         };
-        auto stack_get = [&](uint32_t slot, uint32_t& ref, float& t) {
-            if (!kDeep || slot < lds_entries) { ref = stack_ref[__umul24(slot, trav_threads) + tid]; t = stack_t[__umul24(slot, trav_threads) + tid]; }
-            else { ref = my_overflow[(size_t)(2 * (slot - lds_entries)) * overflow_stride]; t = __uint_as_float(my_overflow[(size_t)(2 * (slot - lds_entries) + 1) * overflow_stride]); }
+        auto stack_pop = [&](uint32_t& ref, float& t) {
+            L.sp--;
+            if (!kDeep) { ref = stack_ref[__umul24(L.sp, trav_threads) + tid]; t = stack_t[__umul24(L.sp, trav_threads) + tid]; return; }
+            L.top = L.top == 0u ? lds_entries - 1u : L.top - 1u;
+            if (L.sp >= L.lo) { const uint32_t at = __umul24(L.top, trav_threads) + tid; ref = stack_ref[at]; t = stack_t[at]; }
+            else { const uint2 e = my_overflow[__umul24(L.sp, trav_threads)]; ref = e.x; t = __uint_as_float(e.y); L.lo = L.sp; }
         };
 
         // the query has run out of scene nodes
@@ -641,8 +668,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             for (;;) {
                 if (!have_next) {
                     if (L.sp == 0) return walk_ended();
-                    L.sp--;
-                    stack_get(L.sp, next_ref, next_t);
+                    stack_pop(next_ref, next_t);
                 }
                 have_next = false;
                 if (!L.shadow && L.hz < next_t) continue;
@@ -670,8 +696,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // slot above the top is written and left unused, so one copy of the pop loop serves both cases
             const bool any = hitA || hitB;
             const bool a_near = tA <= tB;
-            stack_put(L.sp, a_near ? ref_b : ref_a, fmaxf(tA, tB));
-            L.sp += any ? 1u : 0u;
+            stack_push(a_near ? ref_b : ref_a, fmaxf(tA, tB), any);
             return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
         };
 
@@ -836,7 +861,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             xform_ray(itm, L.pdx, L.pdy, L.pdz);
             if (kind == CRT_OBJ_MESH) {
                 L.qinv = recip3(L.qdir());
-                L.entered = idx; L.sp = 0; L.mesh_hit = false;
+                L.entered = idx; L.sp = 0; L.lo = 0; L.top = 0; L.mesh_hit = false;
                 return resolve(true, __float_as_uint(r6.x), 0.0f);
             }
             const f3 pos = L.qpos(), dir = L.qdir();
