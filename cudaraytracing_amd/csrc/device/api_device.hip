@@ -474,14 +474,21 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cam_pos, cam.position, 12); S.dof = cam.dof; S.pixel_size = cam.pixel_size;
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
-    // LDS holds at most kLdsStackEntries stack entries per traversal lane (21 x 832 lanes x 8 bytes = 137 KiB);
-    // deeper trees use the kernel variant whose stack overflows into the side buffer.  CRT_STACK_ENTRIES overrides the
-    // number (tests: the same scene with the whole stack in LDS, or with almost all of it in the side buffer).
-    const uint32_t kLdsStackEntries = crt::knob_value(getenv("CRT_STACK_ENTRIES"), 21, 2, 66);
+    // Block shape first: the LDS left for the traversal stack depends on it.
+    S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
+    // The traversal stack lives in LDS, depth + 2 entries of 8 bytes per traversal lane, beside the block's queues
+    // (18 KiB).  A tree too deep for that (more than 21 entries at 832 lanes) runs the kernel variant for deep trees:
+    // queues of half the size (10 KiB), the LDS holds the top of the stack (23 entries) and older entries move to
+    // device memory.  CRT_STACK_ENTRIES overrides the number of LDS entries (tests: the same scene with the whole
+    // stack in LDS, or with almost all of it in memory).
+    const uint32_t lane_bytes = S.trav_waves * 64 * 8;
+    const uint32_t kLdsLimit = 141 * 1024, kLdsLimitDeep = 150 * 1024;
     const uint32_t stack_total = max_depth + 2;
-    ctx->deep = stack_total > kLdsStackEntries;
-    ctx->stack_overflow = ctx->deep ? stack_total - kLdsStackEntries : 0;
-    S.stack_entries = ctx->deep ? kLdsStackEntries : stack_total;
+    const uint32_t fit = kLdsLimit / lane_bytes, fit_deep = kLdsLimitDeep / lane_bytes;
+    const uint32_t lds_entries_max = crt::knob_value(getenv("CRT_STACK_ENTRIES"), stack_total <= fit ? fit : fit_deep, 2, 66);
+    S.stack_entries = stack_total < lds_entries_max ? stack_total : lds_entries_max;
+    ctx->stack_overflow = stack_total - S.stack_entries;
+    ctx->deep = ctx->stack_overflow > 0 || S.stack_entries * lane_bytes > kLdsLimit;
     S.stack_overflow = ctx->stack_overflow;
     {
         // Drift bound of the scan's candidate mask.  One round trip through node j maps p to fl(tm * fl(itm * p)): its
@@ -559,8 +566,10 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.sched_box_min = crt::knob_value(getenv("CRT_SCHED_BOX_MIN"), ctx->deep ? 32 : 20, 1, 64);
     S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
     S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), ctx->deep ? 16 : 12, 1, 64);
-    S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
-    S.slots = crt::knob_value(getenv("CRT_SLOTS"), 96 * S.trav_waves < kMaxSlots ? 96 * S.trav_waves : kMaxSlots, 64, kMaxSlots);
+    {
+        const uint32_t most = ctx->deep ? kMaxSlotsDeep : kMaxSlots, usual = ctx->deep ? 72 * S.trav_waves : 96 * S.trav_waves;
+        S.slots = crt::knob_value(getenv("CRT_SLOTS"), usual < most ? usual : most, 64, most);
+    }
     S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
     S.serve_low_water = crt::knob_value(getenv("CRT_SERVE_LOW_WATER"), 64, 0, kQueueSize);
     S.serve_patience = crt::knob_value(getenv("CRT_SERVE_PATIENCE"), 64, 0, 1u << 20);
@@ -592,7 +601,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // two LDS arrays (node reference, entry distance) of stack_entries words per traversal thread
     const uint32_t trav_threads = S.trav_waves * 64;
     ctx->lds_bytes = (size_t)S.stack_entries * trav_threads * 4 * 2;
-    if (ctx->lds_bytes > 141 * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");      // 160 KiB less the queues and counters of the block (18 KiB)
+    if (ctx->lds_bytes > (ctx->deep ? 150u : 141u) * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");      // 160 KiB less the queues and counters of the block
     for (int variant = 0; variant < 3; variant++)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_variant(ctx, variant == 1, variant == 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, trace_variant(ctx, false, false), CRT_BLOCK, ctx->lds_bytes));

@@ -424,14 +424,14 @@ struct Lane {
 // slot numbers in LDS; an entry carries the lap number of its position, so a consumer that has claimed a position
 // knows when the producer's write has landed without a second counter.
 constexpr uint32_t kQueueLog = 11, kQueueSize = 1u << kQueueLog;      // ring positions; slots per block <= kQueueSize
+constexpr uint32_t kDeepQueueLog = 10;      // the kernel variant for deep trees: half the slots at most, and the LDS that saves goes to the traversal stack
 constexpr uint32_t kSlotWords = 80;
 constexpr uint32_t kRecRay = 0, kRecHit = 16, kRecPath = 32, kRecShadowEnd = 60, kRecRay2 = 64;
 // A slot may have two queries under way at once: the shadow query of a light sample and the closest-hit query of the
 // next path segment do not depend on each other (the reference runs them one after the other, trace.cu:137-156).
-// The shadow query of such a pair is read from RAY2 and announced in the ray queue as slot | kSecondQuery, its
+// The shadow query of such a pair is read from RAY2 and announced in the ray queue as slot | (ring size of the slot queues), its
 // result goes to word kRecShadowEnd; whichever of the two ends last queues the slot for shading (join_bits).
-constexpr uint32_t kMaxSlots = kQueueSize, kSecondQuery = kMaxSlots;
-constexpr uint32_t kRayQueueLog = kQueueLog + 1, kRayQueueSize = 1u << kRayQueueLog;      // ring of ray queries: up to two per slot
+constexpr uint32_t kMaxSlots = kQueueSize, kMaxSlotsDeep = 1u << kDeepQueueLog;
 constexpr uint32_t kLanePaired = 0x80000000u;        // in Lane::slot: the query is one of a pair
 constexpr uint32_t kPkPaired = 0x100u;               // in the HIT record's first word, beside PK_CLOSEST_DONE: a shadow query ran beside this one
 static_assert(kRecRay2 + 16 <= kSlotWords && kRecShadowEnd >= kRecPath + 28 && kRecShadowEnd < kRecRay2, "slot record layout");
@@ -457,7 +457,7 @@ DEV void ring_st(ring_t* p, uint32_t v) { __hip_atomic_store(p, (ring_t)v, __ATO
 
 // Every lane with `want` appends its slot.  The caller has made the slot's record visible to the block
 // (release fence) before the call.
-template <uint32_t kLog = kQueueLog>
+template <uint32_t kLog>
 DEV void queue_push(uint32_t* tail, ring_t* ring, bool want, uint32_t slot) {
     constexpr uint32_t kSize = 1u << kLog;
     const unsigned long long m = __ballot(want);
@@ -474,7 +474,7 @@ DEV void queue_push(uint32_t* tail, ring_t* ring, bool want, uint32_t slot) {
 // The lanes with `want` claim up to that many entries, but none unless at least min_take are there; a lane that
 // got one returns true and its slot.  One compare-and-swap per wave; when another wave wins it the call
 // takes nothing and the caller comes back later.
-template <uint32_t kLog = kQueueLog>
+template <uint32_t kLog>
 DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const ring_t* ring, bool want, uint32_t min_take, uint32_t slot_limit,
                    uint32_t& slot, uint32_t* abort_flag) {
     constexpr uint32_t kSize = 1u << kLog;
@@ -525,8 +525,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                                                              float* __restrict__ out_t, uint32_t* slot_mem) {
     extern __shared__ uint32_t lds[];
     __shared__ BlockCtl ctl;
-    __shared__ ring_t shade_ring[2][kQueueSize], ray_ring[kRayQueueSize];
-    __shared__ uint32_t join_bits[kMaxSlots / 32];      // bit = slot: one query of the slot's pair has ended
+    constexpr uint32_t kQLog = kDeep ? kDeepQueueLog : kQueueLog, kQSize = 1u << kQLog;      // ring of slots; slots per block <= kQSize
+    constexpr uint32_t kRLog = kQLog + 1u, kRSize = 1u << kRLog, kSecond = kQSize;            // ring of ray queries: up to two per slot
+    __shared__ ring_t shade_ring[2][kQSize], ray_ring[kRSize];
+    __shared__ uint32_t join_bits[kQSize / 32];      // bit = slot: one query of the slot's pair has ended
     __shared__ unsigned long long sect_clock[kMaxWaves], path_sections[kMaxWaves * 8], wave_clock[kMaxWaves * 2];      // counted build only
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6;
@@ -537,13 +539,13 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
 
     // ---- block set-up: every slot starts in the shading queue asking for a pixel
     if (kCount) for (uint32_t i = tid; i < kMaxWaves * 8; i += CRT_BLOCK) path_sections[i] = 0;
-    for (uint32_t i = tid; i < kRayQueueSize; i += CRT_BLOCK) ray_ring[i] = 0;
-    for (uint32_t i = tid; i < kQueueSize; i += CRT_BLOCK) {
+    for (uint32_t i = tid; i < kRSize; i += CRT_BLOCK) ray_ring[i] = 0;
+    for (uint32_t i = tid; i < kQSize; i += CRT_BLOCK) {
         shade_ring[0][i] = 0;
-        shade_ring[1][i] = (ring_t)(i < n_slots ? ((1u << kQueueLog) | i) : 0u);
+        shade_ring[1][i] = (ring_t)(i < n_slots ? ((1u << kQLog) | i) : 0u);
     }
     for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
-    if (tid < kMaxSlots / 32) join_bits[tid] = 0;
+    if (tid < kQSize / 32) join_bits[tid] = 0;
     if (tid == 0) { ctl.shade_head[0] = 0; ctl.shade_tail[0] = 0; ctl.shade_head[1] = 0; ctl.shade_tail[1] = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // those belong to
         auto op_exchange = [&]() {
             const bool post = state == S_POST;
-            const uint32_t my_slot = L.slot & (kMaxSlots - 1u);
+            const uint32_t my_slot = L.slot & (kQSize - 1u);
             const bool paired = (L.slot & kLanePaired) != 0;
             if (post) {
                 uint32_t* rec = slot_rec(my_slot) + kRecHit;
@@ -940,16 +942,16 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 hand_on = (__hip_atomic_fetch_xor(&join_bits[my_slot >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) != 0;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            queue_push(&ctl.shade_tail[0], shade_ring[0], hand_on && (paired || L.pk == PK_CLOSEST_DONE), my_slot);
-            queue_push(&ctl.shade_tail[1], shade_ring[1], hand_on && !paired && L.pk != PK_CLOSEST_DONE, my_slot);
+            queue_push<kQLog>(&ctl.shade_tail[0], shade_ring[0], hand_on && (paired || L.pk == PK_CLOSEST_DONE), my_slot);
+            queue_push<kQLog>(&ctl.shade_tail[1], shade_ring[1], hand_on && !paired && L.pk != PK_CLOSEST_DONE, my_slot);
             if (post) state = S_IDLE;
             uint32_t slot = 0;
-            const bool got = queue_pop<kRayQueueLog>(&ctl.ray_head, &ctl.ray_tail, ray_ring, state == S_IDLE, 1u, kRayQueueSize, slot, &ctl.abort);
+            const bool got = queue_pop<kRLog>(&ctl.ray_head, &ctl.ray_tail, ray_ring, state == S_IDLE, 1u, kRSize, slot, &ctl.abort);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (kCount) { const uint32_t n_got = (uint32_t)__popcll(__ballot(got)); if ((tid & 63u) == 0) tally.cycles[5] += n_got; }
             if (got) {
-                const uint32_t second = slot & kSecondQuery;
-                slot &= kMaxSlots - 1u;
+                const uint32_t second = slot & kSecond;
+                slot &= kQSize - 1u;
                 if (slot >= n_slots) slot = n_slots - 1u;      // only after an abort: stay inside the block's records
                 const uint4* r4 = reinterpret_cast<const uint4*>(slot_rec(slot) + (second ? kRecRay2 : kRecRay));
                 const uint4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
@@ -1497,7 +1499,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const uint32_t fill1 = lds_ld(&ctl.shade_tail[1]) - lds_ld(&ctl.shade_head[1]);
             const uint32_t which = fill1 > fill0 ? 1u : 0u;
             uint32_t slot = 0;
-            const bool have = queue_pop(&ctl.shade_head[which], &ctl.shade_tail[which], shade_ring[which], true, min_take, n_slots, slot, &ctl.abort);
+            const bool have = queue_pop<kQLog>(&ctl.shade_head[which], &ctl.shade_tail[which], shade_ring[which], true, min_take, n_slots, slot, &ctl.abort);
             if (__ballot(have) == 0) {
                 patience++;
                 if (!idle_wait()) break;
@@ -1509,9 +1511,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.turns[3]++; tally.lanes[3] += have; }
             const uint32_t result = which == 0 ? serve(std::true_type{}, have, slot) : serve(std::false_type{}, have, slot);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            queue_push<kRayQueueLog>(&ctl.ray_tail, ray_ring, result == R_RAY || result == R_TWO_RAYS, slot);
-            queue_push<kRayQueueLog>(&ctl.ray_tail, ray_ring, result == R_TWO_RAYS, slot | kSecondQuery);
-            queue_push(&ctl.shade_tail[1], shade_ring[1], result == R_REFETCH, slot);
+            queue_push<kRLog>(&ctl.ray_tail, ray_ring, result == R_RAY || result == R_TWO_RAYS, slot);
+            queue_push<kRLog>(&ctl.ray_tail, ray_ring, result == R_TWO_RAYS, slot | kSecond);
+            queue_push<kQLog>(&ctl.shade_tail[1], shade_ring[1], result == R_REFETCH, slot);
             const unsigned long long retired = __ballot(result == R_RETIRE);
             if (retired != 0 && lane_rank(__ballot(true)) == 0) atomicSub(&ctl.live, (uint32_t)__popcll(retired));
             if (kCount) tally.cycles[3] += __builtin_amdgcn_s_memtime() - t_start;
