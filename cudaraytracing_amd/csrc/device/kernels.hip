@@ -698,7 +698,15 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // slot above the top is written and left unused, so one copy of the pop loop serves both cases
             const bool any = hitA || hitB;
             const bool a_near = tA <= tB;
-            stack_push(a_near ? ref_b : ref_a, fmaxf(tA, tB), any);
+            // The reference puts the far child on the stack even when its own box was missed (objects.cu:216-218); popped
+            // later, such an INTERIOR node is expanded to no effect: the boxes of its children lie inside its own box
+            // (unions of vertex bounds, renderer/bvh.cu:82-98, 160-166) and every step of the slab test is monotone in
+            // the box planes, so both are missed and nothing follows.  Where the stack is the scarce resource (deep
+            // trees) the plain kernels leave such a node out; the counting build keeps it, to count what the reference
+            // counts.  A missed LEAF stays in either case: its triangles are tested, as the reference tests them.
+            bool keep = any;
+            if (!kCount) keep = keep && ((hitA && hitB) || ref_is_leaf(a_near ? ref_b : ref_a));
+            stack_push(a_near ? ref_b : ref_a, fmaxf(tA, tB), keep);
             return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
         };
 
