@@ -474,16 +474,20 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cam_pos, cam.position, 12); S.dof = cam.dof; S.pixel_size = cam.pixel_size;
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
-    // Block shape first: the LDS left for the traversal stack depends on it.
-    S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), CRT_BLOCK / 64 * 13 / 16, 1, CRT_BLOCK / 64 - 1);
+    // Block shape first: the LDS left for the traversal stack depends on it.  12 of the 16 waves walk rays and 4 shade;
+    // a tree too deep for the LDS stack (bound by memory latency, little shading) does better with 13 and 3.
+    const uint32_t kLdsLimit = 141 * 1024, kLdsLimitDeep = 150 * 1024;
+    const uint32_t stack_total = max_depth + 2;
+    {
+        const uint32_t usual = CRT_BLOCK / 64 * 12 / 16;
+        S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), stack_total * usual * 64 * 8 <= kLdsLimit ? usual : usual + 1, 1, CRT_BLOCK / 64 - 1);
+    }
     // The traversal stack lives in LDS, depth + 2 entries of 8 bytes per traversal lane, beside the block's queues
     // (18 KiB).  A tree too deep for that (more than 21 entries at 832 lanes) runs the kernel variant for deep trees:
     // queues of half the size (10 KiB), the LDS holds the top of the stack (23 entries) and older entries move to
     // device memory.  CRT_STACK_ENTRIES overrides the number of LDS entries (tests: the same scene with the whole
     // stack in LDS, or with almost all of it in memory).
     const uint32_t lane_bytes = S.trav_waves * 64 * 8;
-    const uint32_t kLdsLimit = 141 * 1024, kLdsLimitDeep = 150 * 1024;
-    const uint32_t stack_total = max_depth + 2;
     const uint32_t fit = kLdsLimit / lane_bytes, fit_deep = kLdsLimitDeep / lane_bytes;
     const uint32_t lds_entries_max = crt::knob_value(getenv("CRT_STACK_ENTRIES"), stack_total <= fit ? fit : fit_deep, 2, 66);
     S.stack_entries = stack_total < lds_entries_max ? stack_total : lds_entries_max;
