@@ -285,8 +285,9 @@ def main():
         roofline.update({"kernel": "trace_kernel", "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(kernel_ms)),
                          "traffic": traffic, "other": nested,
                          "note": "no MFMA on this path (not a dense contraction). algorithmic work = traversal counters of the counting build "
-                                 "of the kernel (full scene-node scan, as the reference walks it) priced by the rule in bench.py::algorithmic_work, "
-                                 "divided by the measured duration of the plain kernel"})
+                                 "of the kernel (full scene-node scan and every BVH expansion, as the reference walks them) priced by the rule in "
+                                 "bench.py::algorithmic_work, divided by the measured duration of the plain kernel; the plain kernel passes over "
+                                 "scene nodes and BVH children that are certain to be missed, so it fetches less than that (see traffic)"})
 
     if rehearsal and rank == 0 and world > 1:
         # the gathered frame must equal a frame rendered by one context alone
