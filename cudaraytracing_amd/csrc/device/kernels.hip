@@ -704,9 +704,12 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // the box planes, so both are missed and nothing follows.  Where the stack is the scarce resource (deep
             // trees) the plain kernels leave such a node out; the counting build keeps it, to count what the reference
             // counts.  A missed LEAF stays in either case: its triangles are tested, as the reference tests them.
-            bool keep = any;
+            // A closest-hit query pops nothing that lies beyond its hit (objects.cu:190-192), and the hit only comes
+            // closer: a far child that is beyond it already need not go on the stack at all.
+            const float far_t = fmaxf(tA, tB);
+            bool keep = any && (L.shadow || !(L.hz < far_t));
             if (!kCount) keep = keep && ((hitA && hitB) || ref_is_leaf(a_near ? ref_b : ref_a));
-            stack_push(a_near ? ref_b : ref_a, fmaxf(tA, tB), keep);
+            stack_push(a_near ? ref_b : ref_a, far_t, keep);
             return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
         };
 
