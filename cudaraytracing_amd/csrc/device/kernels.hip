@@ -708,7 +708,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // closer: a far child that is beyond it already need not go on the stack at all.
             const float far_t = fmaxf(tA, tB);
             bool keep = any && (L.shadow || !(L.hz < far_t));
-            if (!kCount) keep = keep && ((hitA && hitB) || ref_is_leaf(a_near ? ref_b : ref_a));
+            if (!kCount || follow_mask) keep = keep && ((hitA && hitB) || ref_is_leaf(a_near ? ref_b : ref_a));      // (counting build: only when profiling the plain kernels' walk)
             stack_push(a_near ? ref_b : ref_a, far_t, keep);
             return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
         };
