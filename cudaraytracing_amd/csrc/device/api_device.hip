@@ -926,8 +926,25 @@ int crt_rng_selftest(crt_ctx* ctx, const uint32_t* seeds, const uint32_t* subseq
 }
 
 int crt_math_selftest(crt_ctx* ctx, int fn, const float* x, const float* y, uint32_t n, float* out) {
-    if (!ctx || !x || !out || n == 0 || fn < 0 || fn > 7) return CRT_E_INVALID;
+    if (!ctx || !x || !out || n == 0 || fn < 0 || (fn > 8 && fn != 100)) return CRT_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (fn == 100) {
+        // every float bit pattern through the reciprocal the kernels use and through the division it stands for:
+        // out[0] = number of patterns on which the two differ (x is not read)
+        unsigned long long* d_bad = nullptr;
+        unsigned long long bad = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&d_bad, sizeof bad));
+        int rc = CRT_OK;
+        if (hipMemset(d_bad, 0, sizeof bad) != hipSuccess) rc = CRT_E_HIP;
+        if (rc == CRT_OK) {
+            hipLaunchKernelGGL(rcp_exhaustive_kernel, dim3(4096), dim3(256), 0, nullptr, d_bad);
+            if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rc = CRT_E_HIP;
+        }
+        (void)hipFree(d_bad);
+        if (rc != CRT_OK) return fail(ctx, rc, "reciprocal self-test failed to run");
+        out[0] = (float)bad;
+        return CRT_OK;
+    }
     float *d_x = nullptr, *d_y = nullptr, *d_o = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d_x, n * 4));
     HIP_TRY(ctx, hipMalloc((void**)&d_y, n * 4));

@@ -148,7 +148,15 @@ DEV void xform_ray(const float* c, f2& x, f2& y, f2& z) {
     x = nx; y = ny; z = nz;
 }
 
-DEV f3 recip3(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+DEV f3 recip3(f3 d) {
+    // three reciprocals side by side, and one common way out for the rare operand the short form does not cover
+    f3 r = mk3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
+    if (!(rcp_fast_ok(r.x) && rcp_fast_ok(r.y) && rcp_fast_ok(r.z))) {
+        asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
+        r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    }
+    return r;
+}
 
 // ------------------------------------------------------------------ textures (scene/texture.cu:14-63)
 DEV f3 texel(const uint8_t* __restrict__ p) {
@@ -230,7 +238,7 @@ DEV f3 transmit(f3 incident, f3 normal, float outerIor, float innerIor, bool& ti
 DEV f3 glossy_normal(f3 normal, float glossiness, Rng& rng) {
     const float x = rng_float(rng);
     const float phi = (float)((double)rng_float(rng) * 3.14159265358979323846 * 2.0);
-    const float cos_theta = crtm::det_powf(1 - x, 1.0f / (glossiness + 1.0f));
+    const float cos_theta = crtm::det_powf(1 - x, rcp_ieee(glossiness + 1.0f));
     f3 u, v;
     orthonormals(normal, u, v);
     const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
@@ -320,7 +328,8 @@ DEV NodeMask scan_candidates(const DevScene& S, const BoxPair* __restrict__ pair
     const f2 ox = cx ? f2{pos.x + dp, pos.x - dp} : f2{big, -big};
     const f2 oy = cy ? f2{pos.y + dp, pos.y - dp} : f2{big, -big};
     const f2 oz = cz ? f2{pos.z + dp, pos.z - dp} : f2{big, -big};
-    const float ix = cx ? 1.0f / dir.x : 1.0f, iy = cy ? 1.0f / dir.y : 1.0f, iz = cz ? 1.0f / dir.z : 1.0f;
+    // (a filter: the hardware's reciprocal estimate, 1 ulp, is well inside the 1 / 32 by which the interval is widened)
+    const float ix = cx ? __builtin_amdgcn_rcpf(dir.x) : 1.0f, iy = cy ? __builtin_amdgcn_rcpf(dir.y) : 1.0f, iz = cz ? __builtin_amdgcn_rcpf(dir.z) : 1.0f;
     const float wide = 1.0f / 32.0f;
     uint32_t skip_until = 0;
     // The node records never change during a launch and the index is the same in every lane: they are read through
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const f3 edge1 = mk3(ex.x, ey.x, ez.x), edge2 = mk3(ex.y, ey.y, ez.y), dir = mk3(odx.y, ody.y, odz.y);
             const float det = u.x;
             bool ok = !(det > -CRT_TRI_EPS && det < CRT_TRI_EPS);
-            const float idet = 1 / det;
+            const float idet = rcp_ieee(det);
             const float b1 = idet * w.x;
             ok = ok && !(b1 <= CRT_TRI_EPS || b1 >= 1 + CRT_TRI_EPS);
             const float b2 = idet * w.y;
@@ -1407,7 +1416,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     if (sampled) {
                         next_dir = ndir;
                         if (!(n_prob <= CRT_F_EPS)) {
-                            contrib *= n_mult * (1.0f / n_prob);
+                            contrib *= n_mult * rcp_ieee(n_prob);
                             alive = ++segments < CRT_MAX_SEGMENTS;
                         }
                     }
@@ -1672,9 +1681,25 @@ __global__ void math_selftest_kernel(int fn, const float* __restrict__ x, const 
         case 4: r = crtm::det_atan2f(x[i], y[i]); break;
         case 5: r = crtm::det_asinf(x[i]); break;
         case 6: r = crtm::det_acosf(x[i]); break;
+        case 8: r = rcp_ieee(x[i]); break;
         default: r = crtm::det_tanf(x[i]); break;
     }
     out[i] = r;
+}
+
+// Every one of the 2^32 float bit patterns through rcp_ieee and through the division it stands for; the number of
+// patterns on which they differ (NaN results count as equal) is added to *differences.
+__global__ void rcp_exhaustive_kernel(unsigned long long* differences) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        float x = __uint_as_float((uint32_t)i);
+        const float got = rcp_ieee(x);
+        asm volatile("" : "+v"(x));
+        const float want = 1.0f / x;
+        if (!(want != want && got != got) && __float_as_uint(got) != __float_as_uint(want)) bad++;
+    }
+    if (bad) atomicAdd(differences, bad);
 }
 
 }  // namespace crt

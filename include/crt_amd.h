@@ -312,8 +312,11 @@ int crt_rng_selftest(crt_ctx* ctx, const uint32_t* seeds, const uint32_t* subseq
                      uint32_t n, uint32_t draws, uint32_t* out);
 
 /* Parity hook for the pinned transcendentals: evaluate function `fn`
- * (0 sin, 1 cos, 2 exp, 3 pow(x, y), 4 atan2(x, y), 5 asin, 6 acos, 7 tan)
- * on n host floats on the GPU. */
+ * (0 sin, 1 cos, 2 exp, 3 pow(x, y), 4 atan2(x, y), 5 asin, 6 acos, 7 tan,
+ * 8 the kernels' reciprocal, which stands for the division 1.0f / x)
+ * on n host floats on the GPU.  fn = 100 reads no input: it runs all 2^32
+ * float bit patterns through that reciprocal and through the division on
+ * the device and stores in out[0] the number of patterns on which they differ. */
 int crt_math_selftest(crt_ctx* ctx, int fn, const float* x, const float* y, uint32_t n,
                       float* out);
 

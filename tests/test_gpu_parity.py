@@ -623,3 +623,20 @@ def test_paired_queries_change_nothing(gpu_ctx, monkeypatch, name, w, h, spp):
     monkeypatch.delenv("CRT_PAIR_LIVE", raising=False)
     gpu_ctx.upload(s)
 
+
+def test_reciprocal_equals_division_for_every_float(gpu_ctx):
+    """The kernels compute 1 / x as the hardware estimate plus one fused Newton step, with the division itself for
+    operands or results outside the normal range.  All 2^32 bit patterns are compared on the device; a sample of
+    them, and the special values, are also compared with numpy's division here."""
+    differ = gpu_ctx.math_selftest(100, np.zeros(1, np.float32))
+    assert differ[0] == 0
+    rs = np.random.RandomState(5)
+    x = rs.randint(0, 2 ** 32, 1 << 20, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    x[:12] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, 8.5070587e37, 8.5070597e37, 1.0]
+    got = gpu_ctx.math_selftest(8, x)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore", under="ignore"):
+        want = np.float32(1.0) / x
+    nan = np.isnan(want)
+    assert (np.isnan(got) == nan).all()
+    assert (got.view(np.uint32)[~nan] == want.view(np.uint32)[~nan]).all()
+
