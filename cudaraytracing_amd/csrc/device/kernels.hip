@@ -331,18 +331,24 @@ DEV NodeMask scan_candidates(const DevScene& S, const BoxPair* __restrict__ pair
     // (a filter: the hardware's reciprocal estimate, 1 ulp, is well inside the 1 / 32 by which the interval is widened)
     const float ix = cx ? __builtin_amdgcn_rcpf(dir.x) : 1.0f, iy = cy ? __builtin_amdgcn_rcpf(dir.y) : 1.0f, iz = cz ? __builtin_amdgcn_rcpf(dir.z) : 1.0f;
     const float wide = 1.0f / 32.0f;
+    // plane distances as one fused multiply-add per pair, box * (1 / dir) - origin * (1 / dir): the product on the right
+    // is rounded once more than in (box - origin) * (1 / dir), by at most 2^-24 of its magnitude, so 2^-22 of the
+    // largest such product (over the constrained axes) goes into the margin
+    const f2 oix = ox * ix, oiy = oy * iy, oiz = oz * iz;
+    const float reach = fmaxf(cx ? fmaxf(fabsf(oix.x), fabsf(oix.y)) : 0.0f, fmaxf(cy ? fmaxf(fabsf(oiy.x), fabsf(oiy.y)) : 0.0f, cz ? fmaxf(fabsf(oiz.x), fabsf(oiz.y)) : 0.0f));
+    const float margin = __builtin_fmaf(reach, 0x1p-22f, 1e-6f);
     uint32_t skip_until = 0;
     // The node records never change during a launch and the index is the same in every lane: they are read through
     // the constant address space, i.e. with scalar loads, a whole 64-byte record (nodes i and i + 1) at a time.
     typedef uint32_t u16v __attribute__((ext_vector_type(16)));
     const __attribute__((address_space(4))) u16v* recs = reinterpret_cast<const __attribute__((address_space(4))) u16v*>(reinterpret_cast<uintptr_t>(pairs));
     auto one = [&](uint32_t word, uint32_t i, uint32_t ref, f2 bx, f2 by, f2 bz) -> uint32_t {
-        const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;
+        const f2 tx = __builtin_elementwise_fma(bx, f2{ix, ix}, -oix), ty = __builtin_elementwise_fma(by, f2{iy, iy}, -oiy), tz = __builtin_elementwise_fma(bz, f2{iz, iz}, -oiz);
         float t_in = fmaxf(fminf(tx.x, tx.y), fmaxf(fminf(ty.x, ty.y), fminf(tz.x, tz.y)));
         float t_out = fminf(fmaxf(tx.x, tx.y), fminf(fmaxf(ty.x, ty.y), fmaxf(tz.x, tz.y)));
         // (this is a filter, not path arithmetic: fused multiply-add is fine here)
-        t_in = __builtin_fmaf(-wide, fabsf(t_in), t_in - 1e-6f);
-        t_out = __builtin_fmaf(wide, fabsf(t_out), t_out + 1e-6f);
+        t_in = __builtin_fmaf(-wide, fabsf(t_in), t_in - margin);
+        t_out = __builtin_fmaf(wide, fabsf(t_out), t_out + margin);
         // a NaN bound (cannot arise from finite inputs) fails all three comparisons and so keeps the node
         const bool cand = !((t_in > t_out) | (t_out < -2.0f * FLT_EPSILON) | (t_in > tmax));
         const bool live = i >= skip_until;
