@@ -54,14 +54,18 @@ def algorithmic_work(c, pixels):
 
 
 def kernel_source_digest():
-    """SHA-1 over the sources the trace kernel is built from; a committed counter summary carries the digest of the
+    """SHA-1 over the sources the trace kernel is built from, comments and white space left out (a reworded comment does
+    not make a measurement stale, a changed statement does); a committed counter summary carries the digest of the
     sources it was measured on, so a stale summary is recognised."""
-    import hashlib
+    import hashlib, re
     h = hashlib.sha1()
     for rel in ("cudaraytracing_amd/csrc/device/kernels.hip", "cudaraytracing_amd/csrc/device/dev_scene.h",
                 "cudaraytracing_amd/csrc/crt_detmath.h", "cudaraytracing_amd/csrc/crt_vec.h"):
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, rel), "r", encoding="utf-8", errors="replace") as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)       # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                    # line comments (no string literal of these files holds //)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()
 
 

@@ -8,7 +8,7 @@
 // queue with one wave-aggregated atomic (ballot + mbcnt prefix).
 //
 // Slots, not lanes, own pixels.  Everything a pixel carries from one ray query
-// to the next lives in the slot's 256-byte record in global memory, and two
+// to the next lives in the slot's 320-byte record in global memory, and two
 // kinds of wave pass slots to each other through rings in LDS (positions
 // reserved with one atomic per wave, entries compacted with ballot + mbcnt):
 //   * traversal waves run ray queries.  A lane takes a ready query of whatever
@@ -26,6 +26,10 @@
 //     ray of a new path, the next pixel of a finished slot) for up to 64 slots
 //     at a time, whichever lanes finished them, in turns that are all of one
 //     kind (closest-hit query ended / shadow query ended or pixel needed).
+// When a block runs short of pixels, a pixel's shadow query and the closest-hit
+// query of its next path segment run side by side (they are independent; the
+// results are joined in the reference's order), which shortens the chain of
+// dependent queries that bounds the end of a frame.
 // When a block runs short of pixels, a pixel's shadow query and the closest-hit
 // query of its next path segment run side by side (they are independent; the
 // results are joined in the reference's order), which shortens the chain of
@@ -427,12 +431,14 @@ struct Lane {
 
 // ------------------------------------------------------------------ pixel slots and the block's two queues
 // A block owns S.slots pixel slots.  A slot holds one pixel at a time and everything that pixel carries from one
-// ray query to the next, as one 256-byte record in global memory:
+// ray query to the next, as one 320-byte record in global memory:
 //   words  0..15  RAY   the query to run: written by a shading lane, read by the traversal lane that takes it
 //   words 16..31  HIT   how the query ended: written by that traversal lane, read by a shading lane
 //   words 32..59  PATH  random stream (6), throughput (3), view vector (3), sample, segment, cost, pixel; then what is
 //                       parked while a shadow query runs (continuation direction, flags, light sample, hit
 //                       position) and the pixel's tile: only the shading waves touch it
+//   word      60  how the shadow query of a pair of queries ended
+//   words 64..79  RAY2  the shadow query that runs beside the closest-hit query of RAY (below)
 // Slots, not lanes, own pixels: a traversal lane that finishes a query posts the slot to the block's shading queue
 // and takes whatever query is ready next, a shading lane does the opposite, so both kinds of wave run with their
 // lanes full while any one pixel still sees its operations in the reference's order.  Both queues are rings of
