@@ -1104,8 +1104,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // enough to keep its traversal lanes busy the kernel is bound by throughput and the trade does not pay;
             // once slots have retired (no pixels left to take: the end of a frame, or a small share of one) and fewer
             // than pair_live of them are left, the frame lasts as long as the longest chain, and it does.
-            // (pair_below: pair also while few queries are ready.)
-            const bool pair_now = kClosest && (lds_ld(&ctl.live) < S.pair_live || lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) < S.pair_below);
+            // A frame shared among several GPUs (P.parts > 1) is short of pixels on every one of them sooner or later and
+            // pairs from the start: measured, that is the better trade from two GPUs on.  (pair_below: pair also while
+            // few queries are ready.)
+            const bool pair_now = kClosest && (P.parts > 1u || lds_ld(&ctl.live) < S.pair_live || lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) < S.pair_below);
             uint32_t pk = have ? rec[kRecHit] : (uint32_t)PK_NEW_PATH;
             const bool was_paired = kClosest && (pk & kPkPaired) != 0;
             pk &= ~kPkPaired;
