@@ -583,6 +583,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const bool grouped = kWide && (S.scan_mask & 4u) != 0;
     const bool by_mask = follow_mask && !grouped;
     const bool by_group = follow_mask && grouped;
+    // the first step of a query's scan is taken by the shading wave that sets the query up (write_query)
+    constexpr bool kFirstStepHere = !kCount && !kWide;
     const uint32_t group_shift = S.group_shift;
 
     Tally tally = {};
@@ -1001,6 +1003,12 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
                 // no node of the scene can be hit at all: the query is over before its first box step
                 state = after_scan();
+                // the shading wave has taken the query into the mesh of node c.w already (see write_query): d.z is the root
+                if (kFirstStepHere && (b.w & 4u)) {
+                    L.entered = c.w; L.sp = 0; L.lo = 0; L.top = 0; L.mesh_hit = false;
+                    L.cur = d.z;
+                    state = S_BOX;
+                }
             }
         };
 
@@ -1501,12 +1509,44 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     if (by_mask) node = first < node_count ? first : node_count;
                     if (by_group) node = first < S.group_count ? first << group_shift : node_count;
                 }
-                const f3 rinv = recip3(qdir_);
+                f3 rinv = recip3(qdir_);
+                // The first step of the scan is taken here, where every lane has a query, rather than by the few
+                // traversal lanes of a NODE turn: the box of the lowest candidate (trace.cu:55, 170) and, when the query
+                // has to enter a mesh through it, Node::ToLocal (trace.cu:61, 188).  Same operations on the same values as
+                // op_node's, so nothing changes but who carries them out.  A query that finds the box missed starts at
+                // its next candidate; one that would enter anything but a mesh with an interior root starts as before.
+                uint32_t entered = 0, root = 0;
+                if (kFirstStepHere && by_mask && node < node_count) {
+                    const float4* rp = reinterpret_cast<const float4*>(pairs + node);
+                    const float4 q0 = rp[0], q1 = rp[1], q3 = rp[3];
+                    const uint32_t ref_a = __float_as_uint(q3.x), after_a = node_ref_after(ref_a);
+                    float dA;
+                    const bool hitA = slab(f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, qpos_, rinv, qlimit, dA);
+                    const bool enter = hitA & (qshadow | (dA < CRT_BIGFLOAT));
+                    unsigned long long m = mask.lo & ~(1ull << node);
+                    if (qshadow & !hitA) m &= ~(((1ull << (after_a & 63u)) - 1ull) | (after_a >= 64u ? ~0ull : 0ull)) | ((2ull << node) - 1ull);
+                    if (!enter) {
+                        mask.lo = m;
+                        node = m ? (uint32_t)__ffsll((long long)m) - 1u : node_count;
+                    } else if (node_ref_kind(ref_a) == CRT_OBJ_MESH) {
+                        const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + node);
+                        const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r6 = xp[6];
+                        if (!ref_is_leaf(__float_as_uint(r6.x))) {
+                            const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                            f2 px = f2{qpos_.x, qdir_.x}, py = f2{qpos_.y, qdir_.y}, pz = f2{qpos_.z, qdir_.z};
+                            xform_ray(itm, px, py, pz);
+                            qpos_ = mk3(px.x, py.x, pz.x); qdir_ = mk3(px.y, py.y, pz.y);
+                            rinv = recip3(qdir_);
+                            mask.lo = m;
+                            entered = 4u; root = __float_as_uint(r6.x);
+                        }
+                    }
+                }
                 uint4* ray4 = reinterpret_cast<uint4*>(dst);
                 ray4[0] = uint4{__float_as_uint(qpos_.x), __float_as_uint(qpos_.y), __float_as_uint(qpos_.z), __float_as_uint(qlimit)};
-                ray4[1] = uint4{__float_as_uint(qdir_.x), __float_as_uint(qdir_.y), __float_as_uint(qdir_.z), (qshadow ? 1u : 0u) | (two ? 2u : 0u)};
+                ray4[1] = uint4{__float_as_uint(qdir_.x), __float_as_uint(qdir_.y), __float_as_uint(qdir_.z), (qshadow ? 1u : 0u) | (two ? 2u : 0u) | entered};
                 ray4[2] = uint4{__float_as_uint(rinv.x), __float_as_uint(rinv.y), __float_as_uint(rinv.z), node};
-                ray4[3] = uint4{(uint32_t)mask.lo, (uint32_t)(mask.lo >> 32), (uint32_t)mask.hi, (uint32_t)(mask.hi >> 32)};
+                ray4[3] = uint4{(uint32_t)mask.lo, (uint32_t)(mask.lo >> 32), kWide ? (uint32_t)mask.hi : root, (uint32_t)(mask.hi >> 32)};
             };
             if (result == R_RAY || result == R_TWO_RAYS) {
                 write_query(rec + kRecRay, rpos, rdir, rlimit, rshadow);
