@@ -162,6 +162,39 @@ DEV f3 recip3(f3 d) {
     return r;
 }
 
+// Unit sphere / unit plane against a ray in the object's own space (Sphere::IntersectRay / IntersectShadowRay,
+// Plane::IntersectRay / IntersectShadowRay: scene/objects.cu:7-159).  hz: the closest hit so far.
+DEV bool unit_object_hit(bool sphere, f3 pos, f3 dir, bool shadow, float limit, float hz, float& t, bool& front) {
+    bool got = false;
+    front = true; t = 0;
+    if (sphere) {
+        if (!(dot(dir, pos) >= 0)) {
+            const float a = dot(dir, dir);
+            const float b = dot(dir, pos) * 2;
+            const float c = dot(pos, pos) - 1;
+            const float det = b * b - 4 * a * c;
+            if (!(det < 0)) {
+                const float sq = sqrtf(det);
+                const float tf = (-b - sq) / (2 * a);
+                const float tb = (-b + sq) / (2 * a);
+                if (shadow) got = (tf >= 0 && tf <= limit) || (tb >= 0 && tb <= limit);
+                else if (tf >= 0) { if (!(tf >= hz)) { got = true; t = tf; front = true; } }
+                else if (!(tb < 0) && !(tb >= hz)) { got = true; t = tb; front = false; }
+            }
+        }
+    } else {
+        if (!(dir.z == 0)) {
+            t = -pos.z / dir.z;
+            const bool in_range = shadow ? !(t < 0 || t >= limit) : !(t < 0 || t >= hz);
+            if (in_range && ((dir.z < 0) || (dir.z > 0))) {
+                const f3 p = pos + t * dir;
+                if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
+            }
+        }
+    }
+    return got;
+}
+
 // ------------------------------------------------------------------ textures (scene/texture.cu:14-63)
 DEV f3 texel(const uint8_t* __restrict__ p) {
     return mk3((float)p[0], (float)p[1], (float)p[2]) * (1.0f / 256.0f);
@@ -901,35 +934,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 return resolve(true, __float_as_uint(r6.x), 0.0f);
             }
             const f3 pos = L.qpos(), dir = L.qdir();
-            bool got = false, front = true;
-            float t = 0;
-            if (kind == CRT_OBJ_SPHERE) {
-                TALLY(sphere_tests);
-                if (!(dot(dir, pos) >= 0)) {
-                    const float a = dot(dir, dir);
-                    const float b = dot(dir, pos) * 2;
-                    const float c = dot(pos, pos) - 1;
-                    const float det = b * b - 4 * a * c;
-                    if (!(det < 0)) {
-                        const float sq = sqrtf(det);
-                        const float tf = (-b - sq) / (2 * a);
-                        const float tb = (-b + sq) / (2 * a);
-                        if (L.shadow) got = (tf >= 0 && tf <= L.limit) || (tb >= 0 && tb <= L.limit);
-                        else if (tf >= 0) { if (!(tf >= L.hz)) { got = true; t = tf; front = true; } }
-                        else if (!(tb < 0) && !(tb >= L.hz)) { got = true; t = tb; front = false; }
-                    }
-                }
-            } else {
-                TALLY(plane_tests);
-                if (!(dir.z == 0)) {
-                    t = -pos.z / dir.z;
-                    const bool in_range = L.shadow ? !(t < 0 || t >= L.limit) : !(t < 0 || t >= L.hz);
-                    if (in_range && ((dir.z < 0) || (dir.z > 0))) {
-                        const f3 p = pos + t * dir;
-                        if (!(fabsf(p.x) > 1 || fabsf(p.y) > 1)) { got = true; front = dir.z < 0; }
-                    }
-                }
-            }
+            if (kind == CRT_OBJ_SPHERE) TALLY(sphere_tests); else TALLY(plane_tests);
+            bool front;
+            float t;
+            const bool got = unit_object_hit(kind == CRT_OBJ_SPHERE, pos, dir, L.shadow, L.limit, L.hz, t, front);
             L.entered = idx;
             L.mesh_hit = false;
             if (got) {
@@ -1008,6 +1016,18 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     L.entered = c.w; L.sp = 0; L.lo = 0; L.top = 0; L.mesh_hit = false;
                     L.cur = d.z;
                     state = S_BOX;
+                }
+                // ... or through a sphere / plane: b.w has the outcome, the hit (if any) is in c and d.z
+                if (kFirstStepHere && (b.w & 8u)) {
+                    L.entered = c.w;
+                    L.mesh_hit = (b.w & 16u) != 0;
+                    if (L.mesh_hit) {
+                        L.hz = __uint_as_float(d.z);
+                        L.h_kind = (b.w & 64u) ? H_SPHERE : H_PLANE;
+                        L.h_node = c.w; L.h_front = (b.w & 32u) != 0;
+                        L.h_a = __uint_as_float(c.x); L.h_b = __uint_as_float(c.y); L.h_c = c.z;
+                    }
+                    state = walk_ended();
                 }
             }
         };
@@ -1528,17 +1548,34 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     if (!enter) {
                         mask.lo = m;
                         node = m ? (uint32_t)__ffsll((long long)m) - 1u : node_count;
-                    } else if (node_ref_kind(ref_a) == CRT_OBJ_MESH) {
+                    } else {
+                        const uint32_t kind = node_ref_kind(ref_a);
                         const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + node);
                         const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r6 = xp[6];
-                        if (!ref_is_leaf(__float_as_uint(r6.x))) {
-                            const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-                            f2 px = f2{qpos_.x, qdir_.x}, py = f2{qpos_.y, qdir_.y}, pz = f2{qpos_.z, qdir_.z};
-                            xform_ray(itm, px, py, pz);
-                            qpos_ = mk3(px.x, py.x, pz.x); qdir_ = mk3(px.y, py.y, pz.y);
-                            rinv = recip3(qdir_);
-                            mask.lo = m;
-                            entered = 4u; root = __float_as_uint(r6.x);
+                        const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                        f2 px = f2{qpos_.x, qdir_.x}, py = f2{qpos_.y, qdir_.y}, pz = f2{qpos_.z, qdir_.z};
+                        xform_ray(itm, px, py, pz);
+                        const f3 lpos = mk3(px.x, py.x, pz.x), ldir = mk3(px.y, py.y, pz.y);
+                        if (kind == CRT_OBJ_MESH) {
+                            if (!ref_is_leaf(__float_as_uint(r6.x))) {
+                                qpos_ = lpos; qdir_ = ldir;
+                                rinv = recip3(qdir_);
+                                mask.lo = m;
+                                entered = 4u; root = __float_as_uint(r6.x);
+                            }
+                        } else {
+                            // sphere / plane: the test itself as well; the query goes on from the point where it leaves the node
+                            // (in place of 1 / direction, which that step computes afresh, the record carries the local hit point)
+                            bool front;
+                            float t;
+                            const bool got = unit_object_hit(kind == CRT_OBJ_SPHERE, lpos, ldir, qshadow, qlimit, CRT_BIGFLOAT, t, front);
+                            if (!(qshadow && got)) {      // (a blocked shadow query: left to the traversal lane, which ends it)
+                                qpos_ = lpos; qdir_ = ldir;
+                                rinv = lpos + t * ldir;
+                                mask.lo = m;
+                                entered = 8u | (got ? 16u : 0u) | (front ? 32u : 0u) | (kind == CRT_OBJ_SPHERE ? 64u : 0u);
+                                root = __float_as_uint(t);
+                            }
                         }
                     }
                 }
