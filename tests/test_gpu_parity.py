@@ -600,6 +600,62 @@ def test_many_instances_of_one_mesh(gpu_ctx, tmp_path, n_side):
     assert full == cnt
 
 
+def test_first_scan_step_cases(gpu_ctx, tmp_path):
+    """The shading wave takes the first step of every query's node scan for scenes of up to 64 nodes.  This scene puts
+    each kind of first node in front of many rays: a mesh whose BVH root is a leaf (two triangles: left to the traversal
+    lane), a mesh with an interior root, spheres and planes with children (a shadow ray that misses one skips its
+    subtree), spheres between the lights and the floor (shadow queries blocked by their first node), glass."""
+    _instance_grid_xml(tmp_path, 1)                     # writes blob.obj (128 triangles)
+    (tmp_path / "quad.obj").write_text("v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nf 1 2 3\nf 1 3 4\n")
+    rs = np.random.RandomState(11)
+    body = []
+    for k in range(6):
+        x, y = rs.uniform(-5, 5, 2)
+        body.append(f'<object type="obj" name="quad.obj" material="m{k % 3}"><scale value="{rs.uniform(0.6, 1.4):.3f}"/>'
+                    f'<rotate angle="{rs.uniform(0, 360):.2f}" x="{rs.uniform(-1, 1):.3f}" y="{rs.uniform(-1, 1):.3f}" z="1"/>'
+                    f'<translate x="{x:.3f}" y="{y:.3f}" z="{rs.uniform(0.5, 3):.3f}"/></object>')
+    for k in range(8):
+        x, y = rs.uniform(-6, 6, 2)
+        kind = "sphere" if k % 4 else "plane"
+        body.append(f'<object type="{kind}" name="s{k}" material="m{(k + 1) % 3}"><scale x="{rs.uniform(0.5, 1.2):.3f}" y="{rs.uniform(0.5, 1.2):.3f}" z="{rs.uniform(0.5, 1.2):.3f}"/>'
+                    f'<rotate angle="{rs.uniform(0, 360):.2f}" x="{rs.uniform(-1, 1):.3f}" y="1" z="{rs.uniform(-1, 1):.3f}"/>'
+                    f'<translate x="{x:.3f}" y="{y:.3f}" z="{rs.uniform(1, 5):.3f}"/>'
+                    f'<object type="obj" name="blob.obj" material="m{k % 3}"><scale value="0.5"/><translate x="0.4" y="-0.3" z="1.6"/></object>'
+                    f'<object type="sphere" name="c{k}" material="m2"><scale value="0.4"/><translate x="-1.2" z="0.3"/></object></object>')
+    body.append('<object type="plane" name="floor" material="m0"><scale value="30"/></object>')
+    mats = ['<material type="blinn" name="m0"><diffuse r="0.8" g="0.7" b="0.6"/><specular value="0.2"/><glossiness value="20"/></material>',
+            '<material type="blinn" name="m1"><diffuse r="0.2" g="0.5" b="0.8"/><specular value="0.7"/><glossiness value="60"/></material>',
+            '<material type="blinn" name="m2"><diffuse value="0.05"/><specular value="0.1"/><glossiness value="100"/>'
+            '<refraction value="0.85" index="1.5"/><absorption r="0.02" g="0.01" b="0.03"/></material>']
+    lights = ['<light type="point" name="l0"><intensity value="400"/><position x="4" y="-6" z="12"/><size value="1.5"/></light>',
+              '<light type="point" name="l1"><intensity value="150"/><position x="-7" y="-3" z="7"/><size value="0.5"/></light>']
+    cam = ('<camera><position x="0" y="-17" z="8"/><target x="0" y="0" z="1"/><up x="0" y="0" z="1"/><fov value="44"/>'
+           '<width value="288"/><height value="176"/></camera>')
+    (tmp_path / "first.xml").write_text("<xml><scene>" + "".join(body + mats + lights) + "</scene>" + cam + "</xml>")
+    s = crt.Scene.load_xml(str(tmp_path / "first.xml"), str(tmp_path))
+    assert 30 < s.desc().node_count <= 64 and s.desc().mesh_count == 2
+    flat = str(tmp_path / "first.crtscene")
+    s.save_file(flat)
+    o = orc.OracleScene(flat)
+    gpu_ctx.upload(s)
+    gpu_ctx.clear()
+    gpu_ctx.render_pass(0, 6)
+    acc = gpu_ctx.read_accumulators()
+    ref, cnt = o.render(0, 6, count=True)
+    for k, n in enumerate(("results", "normals", "albedos")):
+        assert same(acc[k], ref[k]), n
+    st = gpu_ctx.stats()
+    assert (st["closest_rays"], st["shadow_rays"]) == (cnt["closest_rays"], cnt["shadow_rays"])
+    assert cnt["sphere_tests"] > 0 and cnt["plane_tests"] > 0 and cnt["tri_tests"] > 0
+    gpu_ctx.clear()
+    gpu_ctx.render_pass_counted(0, 6)
+    assert same(gpu_ctx.read_accumulators()[0], ref[0])
+    chk = gpu_ctx.scan_check()
+    assert chk["checks"] > 0 and chk["violations"] == 0
+    full = gpu_ctx.stats(); full.pop("texel_quads"); cnt.pop("texel_quads")
+    assert full == cnt
+
+
 @pytest.mark.parametrize("name,w,h,spp", [("final_frame0042", 640, 360, 8), ("proj5_glasspot", 480, 270, 6), ("proj7_checkerboard", 480, 270, 8)])
 def test_paired_queries_change_nothing(gpu_ctx, monkeypatch, name, w, h, spp):
     """A pixel's shadow query and the closest-hit query of its next path segment may run side by side or one after the
