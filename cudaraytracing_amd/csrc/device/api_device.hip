@@ -570,6 +570,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.sched_box_min = crt::knob_value(getenv("CRT_SCHED_BOX_MIN"), ctx->deep ? 32 : 20, 1, 64);
     S.sched_special_min = crt::knob_value(getenv("CRT_SCHED_SPECIAL_MIN"), 6, 1, 64);
     S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), ctx->deep ? 16 : 12, 1, 64);
+    S.first_step = crt::knob_value(getenv("CRT_FIRST_STEP"), 96, 0, 1u << 20);
     {
         const uint32_t most = ctx->deep ? kMaxSlotsDeep : kMaxSlots, usual = ctx->deep ? 72 * S.trav_waves : 96 * S.trav_waves;
         S.slots = crt::knob_value(getenv("CRT_SLOTS"), usual < most ? usual : most, 64, most);

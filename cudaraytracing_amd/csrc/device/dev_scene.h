@@ -123,6 +123,7 @@ struct DevScene {
     uint32_t serve_low_water;        // ... while at least this many queries are ready for the traversal lanes ...
     uint32_t serve_patience;         // ... but for no more than this many polls
     uint32_t serve_priority;         // shading waves run at raised instruction-issue priority
+    uint32_t first_step;             // the shading wave that sets a query up also takes the first step of its node scan while at least this many queries wait for traversal lanes
     uint32_t pair_live;              // ... or while fewer than this many of the block's slots still hold a pixel
     uint32_t pair_below;             // a light sample's shadow query and the next segment's query start together while fewer than this many queries wait for traversal lanes
     unsigned long long watchdog_ticks;   // 100 MHz ticks a wave may find nothing to do before it reports a protocol error

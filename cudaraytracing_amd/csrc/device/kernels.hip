@@ -1135,6 +1135,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // A frame shared among several GPUs (P.parts > 1) is short of pixels on every one of them sooner or later and
             // pairs from the start: measured, that is the better trade from two GPUs on.  (pair_below: pair also while
             // few queries are ready.)
+            // The first step of a query's node scan (write_query) is taken here only while the traversal lanes have queries in
+            // reserve: when they run dry the shading waves are what the block waits for, and they keep their turns short.
+            const bool first_now = kFirstStepHere && lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) >= S.first_step;
             const bool pair_now = kClosest && (P.parts > 1u || lds_ld(&ctl.live) < S.pair_live || lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) < S.pair_below);
             uint32_t pk = have ? rec[kRecHit] : (uint32_t)PK_NEW_PATH;
             const bool was_paired = kClosest && (pk & kPkPaired) != 0;
@@ -1536,7 +1539,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 // op_node's, so nothing changes but who carries them out.  A query that finds the box missed starts at
                 // its next candidate; one that would enter anything but a mesh with an interior root starts as before.
                 uint32_t entered = 0, root = 0;
-                if (kFirstStepHere && by_mask && node < node_count) {
+                if (first_now && by_mask && node < node_count) {
                     const float4* rp = reinterpret_cast<const float4*>(pairs + node);
                     const float4 q0 = rp[0], q1 = rp[1], q3 = rp[3];
                     const uint32_t ref_a = __float_as_uint(q3.x), after_a = node_ref_after(ref_a);
