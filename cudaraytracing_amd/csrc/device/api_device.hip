@@ -475,12 +475,21 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     memcpy(S.cX, cam.cX, 12); memcpy(S.cY, cam.cY, 12); memcpy(S.top_left, cam.top_left_pixel, 12);
     S.node_count = N; S.light_count = d->light_count; S.env_texture = d->env_texture;
     // Block shape first: the LDS left for the traversal stack depends on it.  12 of the 16 waves walk rays and 4 shade;
-    // a tree too deep for the LDS stack (bound by memory latency, little shading) does better with 13 and 3.
+    // a tree too deep for the LDS stack (bound by memory latency, little shading) does better with 13 and 3.  Scenes
+    // with little to walk through keep the shading waves busier than the traversal waves: with fewer than 8 mesh
+    // nodes 11 + 5 is the better split, without any mesh (spheres and planes only: a query is a few NODE turns) 9 + 7
+    // (measured over the fixture scenes; any split computes the same image).
     const uint32_t kLdsLimit = 141 * 1024, kLdsLimitDeep = 150 * 1024;
     const uint32_t stack_total = max_depth + 2;
     {
         const uint32_t usual = CRT_BLOCK / 64 * 12 / 16;
-        S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), stack_total * usual * 64 * 8 <= kLdsLimit ? usual : usual + 1, 1, CRT_BLOCK / 64 - 1);
+        uint32_t mesh_nodes = 0;
+        for (uint32_t i = 0; i < N; i++) mesh_nodes += d->nodes[i].object_kind == CRT_OBJ_MESH ? 1u : 0u;
+        uint32_t split = usual;
+        if (stack_total * usual * 64 * 8 > kLdsLimit) split = usual + 1;
+        else if (mesh_nodes == 0) split = usual - 3;
+        else if (mesh_nodes < 8) split = usual - 1;
+        S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), split, 1, CRT_BLOCK / 64 - 1);
     }
     // The traversal stack lives in LDS, depth + 2 entries of 8 bytes per traversal lane, beside the block's queues
     // (18 KiB).  A tree too deep for that (more than 21 entries at 832 lanes) runs the kernel variant for deep trees:
