@@ -69,7 +69,7 @@ class BvhArrays(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("closest_rays", "shadow_rays", "paths", "node_box_tests", "node_enters",
                                            "bvh_interior", "bvh_leaves", "tri_tests", "tri_hits", "sphere_tests",
-                                           "plane_tests", "texel_quads")] + [("sched_turns", C.c_uint64 * 8), ("sched_lanes", C.c_uint64 * 8), ("sched_cycles", C.c_uint64 * 8), ("path_cycles", C.c_uint64 * 8), ("scan_checks", C.c_uint64), ("scan_violations", C.c_uint64), ("errors", C.c_uint64)]
+                                           "plane_tests", "texel_quads")] + [("sched_turns", C.c_uint64 * 12), ("sched_lanes", C.c_uint64 * 12), ("sched_cycles", C.c_uint64 * 12), ("path_cycles", C.c_uint64 * 8), ("scan_checks", C.c_uint64), ("scan_violations", C.c_uint64), ("errors", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_[:12]}

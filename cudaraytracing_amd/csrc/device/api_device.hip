@@ -32,6 +32,7 @@ struct crt_ctx {
     uint32_t tile_capacity = 0;
     bool order_valid = false;
     bool deep = false;                         // BVH deeper than the LDS stack: kDeep kernels
+    bool regroup = false;                      // the kernels whose waves regroup queries by operation (kRegroup)
     uint32_t stack_overflow = 0;               // stack entries per thread kept in the side buffer
     bool interleave = false;                   // tile order: expensive and cheap tiles alternate
     bool no_balance = false;                   // CRT_NO_BALANCE=1: always hand tiles out in storage order
@@ -263,7 +264,8 @@ void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_r
 // global memory one block of the trace kernel needs: its pixel-slot records and, for deep trees, the stack overflow
 // columns of its traversal threads
 size_t block_state_bytes(const crt_ctx* ctx) {
-    return (size_t)ctx->S.slots * kSlotWords * 4 + (size_t)ctx->S.trav_waves * 64 * 2 * ctx->stack_overflow * 4;
+    const size_t columns = ctx->regroup ? ctx->S.contexts : ctx->S.trav_waves * 64;
+    return (size_t)ctx->S.slots * kSlotWords * 4 + columns * 2 * ctx->stack_overflow * 4;
 }
 
 // blocks to launch: what stays resident, but no more than gives every traversal lane a pixel
@@ -279,15 +281,16 @@ uint32_t trace_grid(const crt_ctx* ctx, int per_cu) {
 using TraceKernel = void (*)(DevScene, DevPartition, int, const uint32_t*, uint32_t*, DevStats*, int32_t*, int32_t*, float*, uint32_t*);
 
 template <bool kCount, bool kPrimary>
-TraceKernel trace_variant(bool deep, bool wide) {
-    if (deep) return wide ? trace_kernel<kCount, kPrimary, true, true> : trace_kernel<kCount, kPrimary, true, false>;
-    return wide ? trace_kernel<kCount, kPrimary, false, true> : trace_kernel<kCount, kPrimary, false, false>;
+TraceKernel trace_variant(bool deep, bool wide, bool regroup) {
+    if (regroup) return wide ? trace_kernel<kCount, kPrimary, false, true, true> : trace_kernel<kCount, kPrimary, false, false, true>;
+    if (deep) return wide ? trace_kernel<kCount, kPrimary, true, true, false> : trace_kernel<kCount, kPrimary, true, false, false>;
+    return wide ? trace_kernel<kCount, kPrimary, false, true, false> : trace_kernel<kCount, kPrimary, false, false, false>;
 }
 
 TraceKernel trace_variant(const crt_ctx* ctx, bool counted, bool primary) {
     const bool wide = ctx->S.node_count > 64;      // two mask words: 65 to 128 nodes, or groups of nodes beyond that
-    if (primary) return trace_variant<false, true>(ctx->deep, wide);
-    return counted ? trace_variant<true, false>(ctx->deep, wide) : trace_variant<false, false>(ctx->deep, wide);
+    if (primary) return trace_variant<false, true>(ctx->deep, wide, ctx->regroup);
+    return counted ? trace_variant<true, false>(ctx->deep, wide, ctx->regroup) : trace_variant<false, false>(ctx->deep, wide, ctx->regroup);
 }
 
 void launch_trace(crt_ctx* ctx, bool counted, bool primary, uint32_t grid, hipStream_t stream, const DevPartition& P, int samples, const uint32_t* jump,
@@ -498,11 +501,37 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // stack in LDS, or with almost all of it in memory).
     const uint32_t lane_bytes = S.trav_waves * 64 * 8;
     const uint32_t fit = kLdsLimit / lane_bytes, fit_deep = kLdsLimitDeep / lane_bytes;
-    const uint32_t lds_entries_max = crt::knob_value(getenv("CRT_STACK_ENTRIES"), stack_total <= fit ? fit : fit_deep, 2, 66);
-    S.stack_entries = stack_total < lds_entries_max ? stack_total : lds_entries_max;
-    ctx->stack_overflow = stack_total - S.stack_entries;
-    ctx->deep = ctx->stack_overflow > 0 || S.stack_entries * lane_bytes > kLdsLimit;
+    ctx->regroup = crt::knob_value(getenv("CRT_REGROUP"), 0, 0, 1) != 0;
+    if (ctx->regroup) {
+        // Regrouping kernels: a block has S.contexts query contexts, each with a stack column and 112 bytes of parked
+        // state in LDS; the LDS left beside the rings decides how many stack entries a column holds (the top of the
+        // stack; older entries move to device memory).
+        S.contexts = crt::knob_value(getenv("CRT_CONTEXTS"), S.trav_waves * 64, 64, kMaxContexts) & ~1u;
+        ctx->deep = false;
+        size_t fixed = 0;
+        for (int variant = 0; variant < 3; variant++) {
+            hipFuncAttributes fa;
+            HIP_TRY(ctx, hipFuncGetAttributes(&fa, (const void*)trace_variant(ctx, variant == 1, variant == 2)));
+            if (fa.sharedSizeBytes > fixed) fixed = fa.sharedSizeBytes;
+        }
+        const size_t per_context = (160u * 1024 - fixed) / S.contexts;
+        if (per_context < kContextBytes + 2 * 8) return fail(ctx, CRT_E_LIMIT, "query contexts do not fit in LDS");
+        const uint32_t room = (uint32_t)((per_context - kContextBytes) / 8);
+        const uint32_t entries = crt::knob_value(getenv("CRT_STACK_ENTRIES"), room, 2, room);
+        S.stack_entries = stack_total < entries ? stack_total : entries;
+        ctx->stack_overflow = stack_total - S.stack_entries;
+    } else {
+        const uint32_t lds_entries_max = crt::knob_value(getenv("CRT_STACK_ENTRIES"), stack_total <= fit ? fit : fit_deep, 2, 66);
+        S.stack_entries = stack_total < lds_entries_max ? stack_total : lds_entries_max;
+        ctx->stack_overflow = stack_total - S.stack_entries;
+        ctx->deep = ctx->stack_overflow > 0 || S.stack_entries * lane_bytes > kLdsLimit;
+    }
     S.stack_overflow = ctx->stack_overflow;
+    S.keep_box = crt::knob_value(getenv("CRT_KEEP_BOX"), 40, 1, 65);
+    S.keep_leaf = crt::knob_value(getenv("CRT_KEEP_LEAF"), 40, 1, 65);
+    S.keep_node = crt::knob_value(getenv("CRT_KEEP_NODE"), 40, 1, 65);
+    S.park_min = crt::knob_value(getenv("CRT_PARK_MIN"), 8, 1, 65);
+    S.burst_max = crt::knob_value(getenv("CRT_BURST_MAX"), 16, 1, 1u << 20);
     {
         // Drift bound of the scan's candidate mask.  One round trip through node j maps p to fl(tm * fl(itm * p)): its
         // distance from p is at most |R p + r| (R = tm3 * itm3 - I, r = tm3 * t_itm + t_tm: the stored matrices are
@@ -614,8 +643,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
 
     // two LDS arrays (node reference, entry distance) of stack_entries words per traversal thread
     const uint32_t trav_threads = S.trav_waves * 64;
-    ctx->lds_bytes = (size_t)S.stack_entries * trav_threads * 4 * 2;
-    if (ctx->lds_bytes > (ctx->deep ? 150u : 141u) * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");      // 160 KiB less the queues and counters of the block
+    ctx->lds_bytes = ctx->regroup ? (size_t)S.contexts * (S.stack_entries * 8 + kContextBytes) : (size_t)S.stack_entries * trav_threads * 4 * 2;
+    if (!ctx->regroup && ctx->lds_bytes > (ctx->deep ? 150u : 141u) * 1024) return fail(ctx, CRT_E_LIMIT, "traversal stack does not fit in LDS");      // 160 KiB less the queues and counters of the block
     for (int variant = 0; variant < 3; variant++)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)trace_variant(ctx, variant == 1, variant == 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->blocks_per_cu, trace_variant(ctx, false, false), CRT_BLOCK, ctx->lds_bytes));
@@ -895,7 +924,8 @@ int crt_get_stats(crt_ctx* ctx, crt_stats* out) {
     out->node_box_tests = s.node_box_tests; out->node_enters = s.node_enters; out->bvh_interior = s.bvh_interior;
     out->bvh_leaves = s.bvh_leaves; out->tri_tests = s.tri_tests; out->tri_hits = s.tri_hits;
     out->sphere_tests = s.sphere_tests; out->plane_tests = s.plane_tests; out->texel_quads = s.texel_quads;
-    for (int k = 0; k < 8; k++) { out->sched_turns[k] = s.sched_turns[k]; out->sched_lanes[k] = s.sched_lanes[k]; out->sched_cycles[k] = s.sched_cycles[k]; out->path_cycles[k] = s.path_cycles[k]; }
+    for (int k = 0; k < 12; k++) { out->sched_turns[k] = s.sched_turns[k]; out->sched_lanes[k] = s.sched_lanes[k]; out->sched_cycles[k] = s.sched_cycles[k]; }
+    for (int k = 0; k < 8; k++) out->path_cycles[k] = s.path_cycles[k];
     out->scan_checks = s.scan_checks; out->scan_violations = s.scan_violations;
     out->errors = s.errors;
     if (s.errors) return fail(ctx, CRT_E_HIP, "the trace kernel reported " + std::to_string(s.errors) + " queue protocol error(s): the image is incomplete");

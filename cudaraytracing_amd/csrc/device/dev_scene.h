@@ -125,6 +125,11 @@ struct DevScene {
     uint32_t serve_priority;         // shading waves run at raised instruction-issue priority
     uint32_t first_step;             // the shading wave that sets a query up also takes the first step of its node scan while at least this many queries wait for traversal lanes
     uint32_t pair_live;              // ... or while fewer than this many of the block's slots still hold a pixel
+    // regrouping kernel: query contexts of a block, and how a traversal wave sticks to the operation it runs
+    uint32_t contexts;               // query contexts (stack column + parked state) per block, 0: the kernel without regrouping
+    uint32_t keep_box, keep_leaf, keep_node;   // the operation runs again without a vote while this many lanes want it
+    uint32_t park_min;               // lanes that wait for another operation are parked once they are this many (or their lanes are needed)
+    uint32_t burst_max;              // turns of one operation between two votes, at most
     uint32_t pair_below;             // a light sample's shadow query and the next segment's query start together while fewer than this many queries wait for traversal lanes
     unsigned long long watchdog_ticks;   // 100 MHz ticks a wave may find nothing to do before it reports a protocol error
     // Candidate mask of the scene-node scan (see scan_candidates in kernels.hip).  drift_rel / drift_abs bound how
@@ -170,7 +175,7 @@ struct DevStats {
     unsigned long long closest_rays, shadow_rays, paths;
     unsigned long long node_box_tests, node_enters, bvh_interior, bvh_leaves;
     unsigned long long tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
-    unsigned long long sched_turns[8], sched_lanes[8], sched_cycles[8];
+    unsigned long long sched_turns[12], sched_lanes[12], sched_cycles[12];
     unsigned long long path_cycles[8];
     unsigned long long scan_checks, scan_violations;   // counted build: box hits of the scan checked against the candidate mask
     unsigned long long errors;                         // waves that gave up waiting on the block's queues (must stay 0)

@@ -118,9 +118,9 @@ DEV void rng_init(Rng& s, uint32_t seed_lo, const uint32_t* __restrict__ jump) {
 struct Tally {
     uint32_t closest_rays, shadow_rays, paths;
     uint32_t node_box_tests, node_enters, bvh_interior, bvh_leaves, tri_tests, tri_hits, sphere_tests, plane_tests, texel_quads;
-    uint32_t turns[8], lanes[8];     // per operation: 0 box, 1 triangle, 2 transform, 3 shading, 4 exchange, 5 pixel fetch
+    uint32_t turns[12], lanes[12];   // per operation: 0 box, 1 triangle, 2 transform, 3 shading, 4 exchange, 5 pixel fetch, 8 park, 9 unpark
     uint32_t scan_checks, scan_violations;
-    unsigned long long cycles[8];
+    unsigned long long cycles[12];
 };
 #define TALLY(field) do { if (kCount) tally.field++; } while (0)
 
@@ -423,7 +423,8 @@ DEV void acc_add(float* __restrict__ p, f3 v) {
 //          (world -> local, sphere / plane test or BVH root)
 //   POST   the query has ended: its result has to be handed to the shading waves
 //   IDLE   the lane has no query: it takes the next one from the block's ray queue
-enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_NODE = 2, S_POST = 3, S_IDLE = 4 };
+//   EMPTY  (regrouping kernel) the lane holds no query context; an IDLE lane holds a free one
+enum : uint32_t { S_BOX = 0, S_LEAF = 1, S_NODE = 2, S_POST = 3, S_IDLE = 4, S_EMPTY = 5 };
 enum : uint32_t { H_NONE = 0, H_SPHERE = 1, H_PLANE = 2, H_MESH = 3 };
 // why a slot is in the shading queue
 enum : uint32_t { PK_NEW_PATH = 0, PK_CLOSEST_DONE = 1, PK_SHADOW_CLEAR = 2, PK_SHADOW_BLOCKED = 3, PK_FETCH = 4 };
@@ -432,6 +433,7 @@ enum : uint32_t { R_NONE = 0, R_RAY = 1, R_REFETCH = 2, R_RETIRE = 3, R_TWO_RAYS
 constexpr uint32_t kPendExit = 0x20000000u;     // NODE: leave the mesh of node `entered` first
 
 struct Lane {
+    uint32_t col;                   // stack column: the lane's own, or (regrouping kernel) the query context the lane holds
     uint32_t slot;                  // pixel slot whose query this lane is running
     uint32_t pk;                    // how the query ended
     // current ray query (closest hit or shadow)
@@ -490,12 +492,18 @@ constexpr uint32_t kLanePaired = 0x80000000u;        // in Lane::slot: the query
 constexpr uint32_t kPkPaired = 0x100u;               // in the HIT record's first word, beside PK_CLOSEST_DONE: a shadow query ran beside this one
 static_assert(kRecRay2 + 16 <= kSlotWords && kRecShadowEnd >= kRecPath + 28 && kRecShadowEnd < kRecRay2, "slot record layout");
 constexpr uint32_t kMaxWaves = 16;
+constexpr uint32_t kContextLog = 10, kMaxContexts = 1u << kContextLog;      // query contexts of a block (regrouping kernel)
+constexpr uint32_t kContextBytes = 112;      // the parked part of a context: 7 x 16 bytes
+
+// The rings of a block, as indices into BlockCtl::head / tail (one array each, so that a wave reads all fills with
+// two LDS loads).  kQBox .. kQIdle: query contexts parked by the operation they wait for (the values equal the lane
+// states S_BOX .. S_IDLE); kQRay: slots whose next query waits for a traversal lane; kQShade0 / kQShade1: slots
+// waiting for a shading lane, in two queues so that a shading turn is all of one kind - [0] a closest-hit query has
+// ended (the full shading code), [1] a shadow query has ended or the slot needs a pixel (little code).
+enum : uint32_t { kQBox = 0, kQLeaf = 1, kQNode = 2, kQPost = 3, kQIdle = 4, kQRay = 5, kQShade0 = 6, kQShade1 = 7 };
 
 struct BlockCtl {
-    // slots waiting for a shading lane, in two queues so that a shading turn is all of one kind: [0] a closest-hit query
-    // has ended (the full shading code), [1] a shadow query has ended or the slot needs a pixel (little code)
-    uint32_t shade_head[2], shade_tail[2];
-    uint32_t ray_head, ray_tail;        // slots whose next query waits for a traversal lane
+    uint32_t head[8], tail[8];
     uint32_t live;                      // slots that still have a pixel or may get one
     uint32_t abort;                     // a wave gave up waiting (a protocol error): every wave leaves
 };
@@ -566,41 +574,53 @@ DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const ring_t* ring, boo
 
 // ------------------------------------------------------------------ the path tracer
 // One launch runs every pixel of the partition.  The waves of a block have fixed roles: the first S.trav_waves
-// run ray queries (BOX / LEAF / XFORM operations, voted per turn), the others run everything between two
+// run ray queries (BOX / LEAF / NODE operations, voted per turn), the others run everything between two
 // queries of a pixel (shading, light and BSDF sampling, new camera rays, taking the next pixel from the global
 // queue).  kDeep: the BVH is deeper than the LDS stack; entries above S.stack_entries live in a per-thread
 // overflow area of the side buffer (rarely reached: a ray's stack is usually a fraction of the tree depth).  kWide: the
 // scene has 65 to 128 nodes, so the candidate mask of the scene-node scan has a second word.
-template <bool kCount, bool kPrimary, bool kDeep, bool kWide>
+// kRegroup: queries, not lanes, own traversal state.  A query in flight has a context in LDS (its stack column and a
+// 112-byte record); a wave keeps the queries that wait for the operation it is running in its lanes' registers and
+// parks the others in the ring of the operation they wait for, where the waves that run that operation pick them up.
+template <bool kCount, bool kPrimary, bool kDeep, bool kWide, bool kRegroup>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(DevScene S, DevPartition P, int samples,
                                                              const uint32_t* __restrict__ jump,
                                                              uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
                                                              int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
                                                              float* __restrict__ out_t, uint32_t* slot_mem) {
+    static_assert(!(kDeep && kRegroup), "the regrouping kernel keeps the top of every stack in LDS already");
     extern __shared__ uint32_t lds[];
     __shared__ BlockCtl ctl;
     constexpr uint32_t kQLog = kDeep ? kDeepQueueLog : kQueueLog, kQSize = 1u << kQLog;      // ring of slots; slots per block <= kQSize
     constexpr uint32_t kRLog = kQLog + 1u, kRSize = 1u << kRLog, kSecond = kQSize;            // ring of ray queries: up to two per slot
+    constexpr uint32_t kCLog = kContextLog, kCSize = kRegroup ? (1u << kCLog) : 1u;           // rings of parked query contexts
     __shared__ ring_t shade_ring[2][kQSize], ray_ring[kRSize];
+    __shared__ ring_t park_ring[5][kCSize];
     __shared__ uint32_t join_bits[kQSize / 32];      // bit = slot: one query of the slot's pair has ended
     __shared__ unsigned long long sect_clock[kMaxWaves], path_sections[kMaxWaves * 8], wave_clock[kMaxWaves * 2];      // counted build only
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6;
     const uint32_t trav_threads = S.trav_waves * 64u;
     const uint32_t n_slots = S.slots;
+    const uint32_t n_ctx = kRegroup ? S.contexts : trav_threads;       // stack columns
     uint32_t* const block_slots = slot_mem + (size_t)blockIdx.x * n_slots * kSlotWords;
     auto slot_rec = [&](uint32_t slot) -> uint32_t* { return block_slots + (size_t)slot * kSlotWords; };
 
-    // ---- block set-up: every slot starts in the shading queue asking for a pixel
+    // ---- block set-up: every slot starts in the shading queue asking for a pixel, every context in the ring of free ones
     if (kCount) for (uint32_t i = tid; i < kMaxWaves * 8; i += CRT_BLOCK) path_sections[i] = 0;
     for (uint32_t i = tid; i < kRSize; i += CRT_BLOCK) ray_ring[i] = 0;
     for (uint32_t i = tid; i < kQSize; i += CRT_BLOCK) {
         shade_ring[0][i] = 0;
         shade_ring[1][i] = (ring_t)(i < n_slots ? ((1u << kQLog) | i) : 0u);
     }
+    if (kRegroup) for (uint32_t i = tid; i < kCSize; i += CRT_BLOCK) {
+        park_ring[kQBox][i] = 0; park_ring[kQLeaf][i] = 0; park_ring[kQNode][i] = 0; park_ring[kQPost][i] = 0;
+        park_ring[kQIdle][i] = (ring_t)(i < n_ctx ? ((1u << kCLog) | i) : 0u);
+    }
     for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
     if (tid < kQSize / 32) join_bits[tid] = 0;
-    if (tid == 0) { ctl.shade_head[0] = 0; ctl.shade_tail[0] = 0; ctl.shade_head[1] = 0; ctl.shade_tail[1] = n_slots; ctl.ray_head = 0; ctl.ray_tail = 0; ctl.live = n_slots; ctl.abort = 0; }
+    if (tid < 8) { ctl.head[tid] = 0; ctl.tail[tid] = tid == kQShade1 ? n_slots : ((kRegroup && tid == kQIdle) ? n_ctx : 0u); }
+    if (tid == 0) { ctl.live = n_slots; ctl.abort = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -623,17 +643,28 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     Tally tally = {};
     // counted build: when the wave started / first found the pixel queue dry (per wave, in LDS)
     if (kCount && (tid & 63u) == 0) { wave_clock[wave * 2] = __builtin_amdgcn_s_memtime(); wave_clock[wave * 2 + 1] = 0; }
-    // a wave that finds nothing to do for this long (100 MHz ticks) reports a protocol error instead of waiting on
+    // A wave that finds nothing to do waits; when NOTHING in the block has moved for S.watchdog_ticks (100 MHz ticks: no
+    // ring has received an entry and no slot has retired) it reports a protocol error instead of waiting on.  Waves
+    // that are merely out of work while a few costly pixels finish their chains of queries see those queries move.
     auto now = []() -> unsigned long long { return __builtin_amdgcn_s_memrealtime(); };
+    auto block_progress = [&]() -> uint32_t {
+        uint32_t sum = lds_ld(&ctl.live);
+        for (int k = 0; k < 8; k++) sum += lds_ld(&ctl.tail[k]);
+        return sum;
+    };
     unsigned long long idle_since = 0;
-    uint32_t idle_polls = 0;
+    uint32_t idle_polls = 0, idle_seen = 0;
     auto idle_wait = [&]() -> bool {       // false: leave the kernel
         if (lds_ld(&ctl.live) == 0 || lds_ld(&ctl.abort) != 0) return false;
-        if (idle_polls == 0) idle_since = now();
-        if ((++idle_polls & 255u) == 0 && now() - idle_since > S.watchdog_ticks) {
-            lds_st(&ctl.abort, 1u);
-            if ((tid & 63u) == 0) atomicAdd(&stats->errors, 1ull);
-            return false;
+        if (idle_polls == 0) { idle_since = now(); idle_seen = block_progress(); }
+        if ((++idle_polls & 255u) == 0) {
+            const uint32_t seen = block_progress();
+            if (seen != idle_seen) { idle_seen = seen; idle_since = now(); }
+            else if (now() - idle_since > S.watchdog_ticks) {
+                lds_st(&ctl.abort, 1u);
+                if ((tid & 63u) == 0) atomicAdd(&stats->errors, 1ull);
+                return false;
+            }
         }
         __builtin_amdgcn_s_sleep(8);
         return true;
@@ -643,44 +674,56 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // =====================================================================================================
         // traversal waves
         // =====================================================================================================
+        // The traversal stack lives in LDS, one column per traversal thread (per query context in the regrouping
+        // kernel), laid out [entry][column]; the plain layout keeps node references and distances in two arrays, the
+        // regrouping one keeps an entry's two words side by side (one 8-byte access).
         uint32_t* __restrict__ stack_ref = lds;
         float* __restrict__ stack_t = reinterpret_cast<float*>(lds + S.stack_entries * trav_threads);
+        uint2* __restrict__ stack_rt = reinterpret_cast<uint2*>(lds);
         const uint32_t lds_entries = S.stack_entries;
-        // overflow of the traversal stack (deep trees): behind the slot records, one column per traversal thread
-        // (laid out [block][entry][thread], reference and distance of an entry side by side: one 8-byte access per lane)
-        uint2* const my_overflow = reinterpret_cast<uint2*>(slot_mem + (size_t)gridDim.x * n_slots * kSlotWords) +
-                                   ((size_t)blockIdx.x * S.stack_overflow * trav_threads + tid);
+        // the parked part of the query contexts follows the stack (regrouping kernel)
+        unsigned char* const ctx_mem = reinterpret_cast<unsigned char*>(lds + 2u * S.stack_entries * n_ctx);
+        // overflow of the traversal stack (deep trees): behind the slot records, one column per stack column
+        // (laid out [block][entry][column], reference and distance of an entry side by side: one 8-byte access per lane)
+        uint2* const block_overflow = reinterpret_cast<uint2*>(slot_mem + (size_t)gridDim.x * n_slots * kSlotWords) +
+                                      (size_t)blockIdx.x * S.stack_overflow * n_ctx;
 
         Lane L = {};
-        uint32_t state = S_IDLE;
+        L.col = tid;
+        uint32_t state = kRegroup ? (uint32_t)S_EMPTY : (uint32_t)S_IDLE;
 
-        // Push / pop.  (slot * threads as a 24-bit product: the full 32-bit multiply issues at a quarter of the rate.)
-        // kDeep: the tree is deeper than the LDS stack.  LDS then holds the TOP of the stack, as a ring of lds_entries
-        // positions: entries [L.lo, L.sp) live at position index % lds_entries (L.top is that position for L.sp), and a
-        // push into a full ring first moves the oldest entry, the one the new one is about to overwrite, to its place
-        // in device memory.  Pops meet memory only when a walk has come back below everything the ring holds.
+        // Push / pop.  (slot * columns as a 24-bit product: the full 32-bit multiply issues at a quarter of the rate.)
+        // kDeep and kRegroup: LDS holds the TOP of the stack, as a ring of lds_entries positions: entries [L.lo, L.sp)
+        // live at position index % lds_entries (L.top is that position for L.sp), and a push into a full ring first
+        // moves the oldest entry, the one the new one is about to overwrite, to its place in device memory.  Pops meet
+        // memory only when a walk has come back below everything the ring holds.
+        constexpr bool kRingStack = kDeep || kRegroup;
         auto stack_push = [&](uint32_t ref, float t, bool keep) {
-            if (!kDeep) {
+            if (!kRingStack) {
                 // written even when it is not kept (the slot above the top, left unused): no branch around the write
                 stack_ref[__umul24(L.sp, trav_threads) + tid] = ref; stack_t[__umul24(L.sp, trav_threads) + tid] = t;
                 L.sp += keep ? 1u : 0u;
             } else if (keep) {
-                const uint32_t at = __umul24(L.top, trav_threads) + tid;
+                const uint32_t at = __umul24(L.top, n_ctx) + L.col;
                 if (L.sp - L.lo == lds_entries) {
-                    my_overflow[__umul24(L.lo, trav_threads)] = uint2{stack_ref[at], __float_as_uint(stack_t[at])};
+                    block_overflow[__umul24(L.lo, n_ctx) + L.col] = kRegroup ? stack_rt[at] : uint2{stack_ref[at], __float_as_uint(stack_t[at])};
                     L.lo++;
                 }
-                stack_ref[at] = ref; stack_t[at] = t;
+                if (kRegroup) stack_rt[at] = uint2{ref, __float_as_uint(t)};
+                else { stack_ref[at] = ref; stack_t[at] = t; }
                 L.sp++;
                 L.top = L.top + 1u == lds_entries ? 0u : L.top + 1u;
             }
         };
         auto stack_pop = [&](uint32_t& ref, float& t) {
             L.sp--;
-            if (!kDeep) { ref = stack_ref[__umul24(L.sp, trav_threads) + tid]; t = stack_t[__umul24(L.sp, trav_threads) + tid]; return; }
+            if (!kRingStack) { ref = stack_ref[__umul24(L.sp, trav_threads) + tid]; t = stack_t[__umul24(L.sp, trav_threads) + tid]; return; }
             L.top = L.top == 0u ? lds_entries - 1u : L.top - 1u;
-            if (L.sp >= L.lo) { const uint32_t at = __umul24(L.top, trav_threads) + tid; ref = stack_ref[at]; t = stack_t[at]; }
-            else { const uint2 e = my_overflow[__umul24(L.sp, trav_threads)]; ref = e.x; t = __uint_as_float(e.y); L.lo = L.sp; }
+            if (L.sp >= L.lo) {
+                const uint32_t at = __umul24(L.top, n_ctx) + L.col;
+                if (kRegroup) { const uint2 e = stack_rt[at]; ref = e.x; t = __uint_as_float(e.y); }
+                else { ref = stack_ref[at]; t = stack_t[at]; }
+            } else { const uint2 e = block_overflow[__umul24(L.sp, n_ctx) + L.col]; ref = e.x; t = __uint_as_float(e.y); L.lo = L.sp; }
         };
 
         // the query has run out of scene nodes
@@ -984,11 +1027,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 hand_on = (__hip_atomic_fetch_xor(&join_bits[my_slot >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) != 0;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            queue_push<kQLog>(&ctl.shade_tail[0], shade_ring[0], hand_on && (paired || L.pk == PK_CLOSEST_DONE), my_slot);
-            queue_push<kQLog>(&ctl.shade_tail[1], shade_ring[1], hand_on && !paired && L.pk != PK_CLOSEST_DONE, my_slot);
+            queue_push<kQLog>(&ctl.tail[kQShade0], shade_ring[0], hand_on && (paired || L.pk == PK_CLOSEST_DONE), my_slot);
+            queue_push<kQLog>(&ctl.tail[kQShade1], shade_ring[1], hand_on && !paired && L.pk != PK_CLOSEST_DONE, my_slot);
             if (post) state = S_IDLE;
             uint32_t slot = 0;
-            const bool got = queue_pop<kRLog>(&ctl.ray_head, &ctl.ray_tail, ray_ring, state == S_IDLE, 1u, kRSize, slot, &ctl.abort);
+            const bool got = queue_pop<kRLog>(&ctl.head[kQRay], &ctl.tail[kQRay], ray_ring, state == S_IDLE, 1u, kRSize, slot, &ctl.abort);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (kCount) { const uint32_t n_got = (uint32_t)__popcll(__ballot(got)); if ((tid & 63u) == 0) tally.cycles[5] += n_got; }
             if (got) {
@@ -1032,7 +1075,136 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             }
         };
 
+        // ---- query contexts (regrouping kernel) --------------------------------------------------------
+        // The parked part of a context: everything of Lane but the column, as seven 16-byte words.
+        auto ctx_store = [&]() {
+            uint4* c = reinterpret_cast<uint4*>(ctx_mem + L.col * kContextBytes);
+            const uint32_t flags = (L.slot & (kQSize - 1u)) | ((L.slot & kLanePaired) ? 0x800u : 0u) | (L.pk << 12) | (L.shadow ? 0x8000u : 0u) |
+                                   (L.mesh_hit ? 0x10000u : 0u) | (L.h_front ? 0x20000u : 0u) | (L.h_kind << 18);
+            c[0] = uint4{__float_as_uint(L.pdx.x), __float_as_uint(L.pdy.x), __float_as_uint(L.pdz.x), __float_as_uint(L.limit)};
+            c[1] = uint4{__float_as_uint(L.pdx.y), __float_as_uint(L.pdy.y), __float_as_uint(L.pdz.y), __float_as_uint(L.hz)};
+            c[2] = uint4{__float_as_uint(L.qinv.x), __float_as_uint(L.qinv.y), __float_as_uint(L.qinv.z), flags};
+            c[3] = uint4{L.node, L.cur, L.entered, L.pend};
+            c[4] = uint4{(uint32_t)L.mask, (uint32_t)(L.mask >> 32), L.sp | (L.lo << 8) | (L.top << 16), L.h_node};
+            c[5] = uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), __float_as_uint(L.h_a)};
+            c[6] = uint4{__float_as_uint(L.h_b), L.h_c, (uint32_t)L.mask_hi, (uint32_t)(L.mask_hi >> 32)};
+        };
+        auto ctx_load = [&]() {
+            const uint4* c = reinterpret_cast<const uint4*>(ctx_mem + L.col * kContextBytes);
+            const uint4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
+            L.pdx = f2{__uint_as_float(c0.x), __uint_as_float(c1.x)};
+            L.pdy = f2{__uint_as_float(c0.y), __uint_as_float(c1.y)};
+            L.pdz = f2{__uint_as_float(c0.z), __uint_as_float(c1.z)};
+            L.limit = __uint_as_float(c0.w); L.hz = __uint_as_float(c1.w);
+            L.qinv = mk3(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z));
+            const uint32_t flags = c2.w;
+            L.slot = (flags & (kQSize - 1u)) | ((flags & 0x800u) ? kLanePaired : 0u);
+            L.pk = (flags >> 12) & 7u; L.shadow = (flags & 0x8000u) != 0; L.mesh_hit = (flags & 0x10000u) != 0;
+            L.h_front = (flags & 0x20000u) != 0; L.h_kind = (flags >> 18) & 3u;
+            L.node = c3.x; L.cur = c3.y; L.entered = c3.z; L.pend = c3.w;
+            L.mask = (unsigned long long)c4.x | ((unsigned long long)c4.y << 32);
+            L.sp = c4.z & 255u; L.lo = (c4.z >> 8) & 255u; L.top = (c4.z >> 16) & 255u; L.h_node = c4.w;
+            L.hpos = mk3(__uint_as_float(c5.x), __uint_as_float(c5.y), __uint_as_float(c5.z)); L.h_a = __uint_as_float(c5.w);
+            L.h_b = __uint_as_float(c6.x); L.h_c = c6.y;
+            if (kWide) L.mask_hi = (unsigned long long)c6.z | ((unsigned long long)c6.w << 32);
+        };
+        // The selected lanes give their contexts up: the state goes to LDS (a free context has none) and the context's
+        // number into the ring of the operation it waits for.
+        auto park = [&](bool sel) {
+            if (kCount) { tally.turns[8]++; tally.lanes[8] += sel; }
+            if (sel && state != S_IDLE) ctx_store();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+            for (uint32_t q = kQBox; q <= kQIdle; q++) queue_push<kCLog>(&ctl.tail[q], park_ring[q], sel && state == q, L.col);
+            if (sel) state = S_EMPTY;
+        };
+        // Empty lanes (at most `most` of them) take contexts that wait for operation q.
+        auto unpark = [&](uint32_t q, uint32_t most) {
+            const unsigned long long empty = __ballot(state == S_EMPTY);
+            const bool want = state == S_EMPTY && lane_rank(empty) < most;
+            uint32_t col = 0;
+            const bool got = queue_pop<kCLog>(&ctl.head[q], &ctl.tail[q], park_ring[q], want, 1u, n_ctx, col, &ctl.abort);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (kCount) { tally.turns[9]++; tally.lanes[9] += got; }
+            if (got) {
+                L.col = col;
+                if (q != kQIdle) ctx_load();
+                state = q;
+            }
+        };
+
         // ---- the scheduler of a traversal wave ------------------------------------------------------
+        if constexpr (kRegroup) {
+            // A wave runs ONE operation with as many of its lanes as it can fill.  At every vote it looks at what its own
+            // lanes wait for and at what is parked, picks the operation with the most queries within reach, parks the
+            // lanes that wait for something else, takes parked queries of its pick into the lanes that are free, and
+            // runs the operation until too few of its lanes want another turn.
+            const uint32_t lane = tid & 63u;
+            for (;;) {
+                unsigned long long t_vote = 0;
+                if (kCount) t_vote = __builtin_amdgcn_s_memtime();
+                const uint32_t nB = (uint32_t)__popcll(__ballot(state == S_BOX)), nL = (uint32_t)__popcll(__ballot(state == S_LEAF));
+                const uint32_t nN = (uint32_t)__popcll(__ballot(state == S_NODE)), nP = (uint32_t)__popcll(__ballot(state == S_POST));
+                const uint32_t nI = (uint32_t)__popcll(__ballot(state == S_IDLE));
+                const uint32_t nE = 64u - nB - nL - nN - nP - nI;
+                // fill of the five context rings and of the ray ring: lane q reads ring q
+                uint32_t fill = 0;
+                if (lane < 6u) { const uint32_t h = lds_ld(&ctl.head[lane]); fill = lds_ld(&ctl.tail[lane]) - h; }      // (head first: never negative)
+                const uint32_t fB = __builtin_amdgcn_readlane(fill, kQBox), fL = __builtin_amdgcn_readlane(fill, kQLeaf);
+                const uint32_t fN = __builtin_amdgcn_readlane(fill, kQNode), fP = __builtin_amdgcn_readlane(fill, kQPost);
+                const uint32_t fI = __builtin_amdgcn_readlane(fill, kQIdle), fR = __builtin_amdgcn_readlane(fill, kQRay);
+                if (kCount) {      // census at every vote
+                    tally.turns[6]++; tally.lanes[6] += (state == S_IDLE || state == S_EMPTY); tally.lanes[7] += state == S_POST;
+                    if (lane == 0) { tally.cycles[6] += fR; tally.cycles[7] += (lds_ld(&ctl.tail[kQShade0]) - lds_ld(&ctl.head[kQShade0])) + (lds_ld(&ctl.tail[kQShade1]) - lds_ld(&ctl.head[kQShade1])); }
+                }
+                // queries within reach per operation.  An exchange serves lanes with a result to post (they then take a
+                // new query like the idle ones) and as many free contexts as the ray ring has queries for.
+                const uint32_t posts = nP + fP;
+                const uint32_t idles = nI + fI;
+                const uint32_t takers = fR > posts ? (fR - posts < idles ? fR - posts : idles) : 0u;
+                const uint32_t dB = nB + fB, dL = nL + fL, dN = nN + fN, dX = posts + takers;
+                auto capped = [](uint32_t d) -> uint32_t { return d < 64u ? d : 64u; };
+                uint32_t best = S_POST, best_d = dX;
+                auto consider = [&](uint32_t op, uint32_t d) { if (capped(d) > capped(best_d) || (capped(d) == capped(best_d) && d > best_d)) { best = op; best_d = d; } };
+                consider(S_NODE, dN); consider(S_LEAF, dL); consider(S_BOX, dB);
+                if (best_d == 0) {
+                    // nothing within reach: no query anywhere in the block that a traversal lane could move
+                    if (!idle_wait()) break;
+                    continue;
+                }
+                idle_polls = 0;
+                // lanes that wait for something else go to the rings when they are many, or when their lanes are needed
+                const bool mine = best == S_POST ? (state == S_POST || state == S_IDLE) : state == best;
+                const bool other = state != S_EMPTY && !mine;
+                const uint32_t n_mine = (uint32_t)__popcll(__ballot(mine)), n_other = 64u - nE - n_mine;
+                const uint32_t reach = capped(best_d) - n_mine;
+                if (n_other != 0 && (n_other >= S.park_min || reach > nE)) park(other);
+                unsigned long long t_start = 0;
+                if (best == S_POST) {
+                    if (fP) unpark(kQPost, 64u);
+                    // free contexts only for the queries that the lanes at hand cannot take
+                    const uint32_t at_hand = (uint32_t)__popcll(__ballot(state == S_POST || state == S_IDLE));
+                    if (fI && fR > at_hand) unpark(kQIdle, fR - at_hand);
+                    if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.cycles[8] += t_start - t_vote; tally.turns[4]++; tally.lanes[4] += (state == S_POST || state == S_IDLE); }
+                    op_exchange();
+                    if (kCount) tally.cycles[4] += __builtin_amdgcn_s_memtime() - t_start;
+                    continue;
+                }
+                if (reach) unpark(best, 64u);
+                if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.cycles[8] += t_start - t_vote; }
+                const uint32_t keep = best == S_BOX ? S.keep_box : (best == S_LEAF ? S.keep_leaf : S.keep_node);
+                uint32_t n_now = (uint32_t)__popcll(__ballot(state == best)), n_first = n_now, turns = 0;
+                // the operation runs again while enough lanes want it, or while nobody has left it (then a vote would come out the same)
+                while (n_now != 0 && (turns == 0 || n_now >= keep || n_now == n_first) && turns < S.burst_max) {
+                    if (best == S_BOX) { if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; } if (state == S_BOX) state = op_box(); }
+                    else if (best == S_LEAF) { if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); }
+                    else { if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_NODE; } if (state == S_NODE) state = op_node(); }
+                    n_now = (uint32_t)__popcll(__ballot(state == best));
+                    turns++;
+                }
+                if (kCount) tally.cycles[best] += __builtin_amdgcn_s_memtime() - t_start;
+            }
+        } else
         for (;;) {
             // Which operation runs this turn.  Box steps are the bulk of the work and run whenever
             // sched_box_min lanes want one.  Otherwise a cheap traversal operation (triangle, transform)
@@ -1058,11 +1230,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 const uint32_t n_special = n_leaf >= n_xf ? n_leaf : n_xf;
                 // idle lanes count toward an exchange only while the ray queue has something for them
                 uint32_t n_take = 0;
-                if (n_idle) { const uint32_t avail = lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head); n_take = avail < n_idle ? avail : n_idle; }
+                if (n_idle) { const uint32_t avail = lds_ld(&ctl.tail[kQRay]) - lds_ld(&ctl.head[kQRay]); n_take = avail < n_idle ? avail : n_idle; }
                 const uint32_t n_ex = n_post + n_take;
                 if (kCount) {      // census at every vote: lanes without a query, and (once per wave) the fill of the two queues
                     tally.turns[6]++; tally.lanes[6] += state == S_IDLE; tally.lanes[7] += state == S_POST;
-                    if ((tid & 63u) == 0) { tally.cycles[6] += lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head); tally.cycles[7] += (lds_ld(&ctl.shade_tail[0]) - lds_ld(&ctl.shade_head[0])) + (lds_ld(&ctl.shade_tail[1]) - lds_ld(&ctl.shade_head[1])); }
+                    if ((tid & 63u) == 0) { tally.cycles[6] += lds_ld(&ctl.tail[kQRay]) - lds_ld(&ctl.head[kQRay]); tally.cycles[7] += (lds_ld(&ctl.tail[kQShade0]) - lds_ld(&ctl.head[kQShade0])) + (lds_ld(&ctl.tail[kQShade1]) - lds_ld(&ctl.head[kQShade1])); }
                 }
                 if (n_ex >= S.sched_exchange_min) best = S_POST;
                 else if (n_special >= S.sched_special_min) best = special;
@@ -1137,8 +1309,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // few queries are ready.)
             // The first step of a query's node scan (write_query) is taken here only while the traversal lanes have queries in
             // reserve: when they run dry the shading waves are what the block waits for, and they keep their turns short.
-            const bool first_now = kFirstStepHere && lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) >= S.first_step;
-            const bool pair_now = kClosest && (P.parts > 1u || lds_ld(&ctl.live) < S.pair_live || lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head) < S.pair_below);
+            const bool first_now = kFirstStepHere && lds_ld(&ctl.tail[kQRay]) - lds_ld(&ctl.head[kQRay]) >= S.first_step;
+            const bool pair_now = kClosest && (P.parts > 1u || lds_ld(&ctl.live) < S.pair_live || lds_ld(&ctl.tail[kQRay]) - lds_ld(&ctl.head[kQRay]) < S.pair_below);
             uint32_t pk = have ? rec[kRecHit] : (uint32_t)PK_NEW_PATH;
             const bool was_paired = kClosest && (pk & kPkPaired) != 0;
             pk &= ~kPkPaired;
@@ -1605,15 +1777,15 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // is better than letting them idle.
             uint32_t min_take = 1;
             {
-                const uint32_t ready = lds_ld(&ctl.ray_tail) - lds_ld(&ctl.ray_head);
+                const uint32_t ready = lds_ld(&ctl.tail[kQRay]) - lds_ld(&ctl.head[kQRay]);
                 if (ready >= S.serve_low_water && patience < S.serve_patience) min_take = S.serve_batch_min;
             }
             // the fuller of the two shading queues
-            const uint32_t fill0 = lds_ld(&ctl.shade_tail[0]) - lds_ld(&ctl.shade_head[0]);
-            const uint32_t fill1 = lds_ld(&ctl.shade_tail[1]) - lds_ld(&ctl.shade_head[1]);
+            const uint32_t fill0 = lds_ld(&ctl.tail[kQShade0]) - lds_ld(&ctl.head[kQShade0]);
+            const uint32_t fill1 = lds_ld(&ctl.tail[kQShade1]) - lds_ld(&ctl.head[kQShade1]);
             const uint32_t which = fill1 > fill0 ? 1u : 0u;
             uint32_t slot = 0;
-            const bool have = queue_pop<kQLog>(&ctl.shade_head[which], &ctl.shade_tail[which], shade_ring[which], true, min_take, n_slots, slot, &ctl.abort);
+            const bool have = queue_pop<kQLog>(&ctl.head[kQShade0 + which], &ctl.tail[kQShade0 + which], shade_ring[which], true, min_take, n_slots, slot, &ctl.abort);
             if (__ballot(have) == 0) {
                 patience++;
                 if (!idle_wait()) break;
@@ -1625,9 +1797,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.turns[3]++; tally.lanes[3] += have; }
             const uint32_t result = which == 0 ? serve(std::true_type{}, have, slot) : serve(std::false_type{}, have, slot);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            queue_push<kRLog>(&ctl.ray_tail, ray_ring, result == R_RAY || result == R_TWO_RAYS, slot);
-            queue_push<kRLog>(&ctl.ray_tail, ray_ring, result == R_TWO_RAYS, slot | kSecond);
-            queue_push<kQLog>(&ctl.shade_tail[1], shade_ring[1], result == R_REFETCH, slot);
+            queue_push<kRLog>(&ctl.tail[kQRay], ray_ring, result == R_RAY || result == R_TWO_RAYS, slot);
+            queue_push<kRLog>(&ctl.tail[kQRay], ray_ring, result == R_TWO_RAYS, slot | kSecond);
+            queue_push<kQLog>(&ctl.tail[kQShade1], shade_ring[1], result == R_REFETCH, slot);
             const unsigned long long retired = __ballot(result == R_RETIRE);
             if (retired != 0 && lane_rank(__ballot(true)) == 0) atomicSub(&ctl.live, (uint32_t)__popcll(retired));
             if (kCount) tally.cycles[3] += __builtin_amdgcn_s_memtime() - t_start;
@@ -1660,7 +1832,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     if (lds_ld(&ctl.abort) != 0 && tid == 0) atomicAdd(&stats->errors, 1ull);
     if (kCount && !kPrimary) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 12; k++) {
             const unsigned long long t = wave_sum(tally.turns[k]), l = wave_sum(tally.lanes[k]);
             if ((tid & 63u) == 0) { atomicAdd(&stats->sched_turns[k], t / 64); atomicAdd(&stats->sched_lanes[k], l); atomicAdd(&stats->sched_cycles[k], tally.cycles[k]); }
         }

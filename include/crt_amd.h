@@ -285,10 +285,12 @@ typedef struct crt_stats {
     uint64_t texel_quads;      /* bilinear texture evaluations */
     /* scheduler detail of the trace kernel (counted build): how often each operation
      * (0 box, 1 triangle, 2 transform, 3 shading, 4 exchange of results for new queries,
-     * 5 pixel fetch) was executed by a wave, and how many lanes took part in total */
-    uint64_t sched_turns[8];
-    uint64_t sched_lanes[8];
-    uint64_t sched_cycles[8];   /* shader clock cycles waves spent in turns of each operation */
+     * 5 pixel fetch) was executed by a wave, and how many lanes took part in total; 6, 7: census at the
+     * votes of the traversal waves; 8 votes that moved queries between waves (lanes: queries given up),
+     * 9 queries taken over from other waves (turns: attempts, lanes: queries), 10, 11 spare */
+    uint64_t sched_turns[12];
+    uint64_t sched_lanes[12];
+    uint64_t sched_cycles[12];  /* shader clock cycles waves spent in turns of each operation */
     uint64_t path_cycles[8];    /* cycles inside the path operation: lights, hit attributes, textures,
                                    light sampling, BSDF sampling, next ray; [6] summed wave
                                    lifetimes, [7] the part of them after the pixel queue ran dry */

@@ -31,6 +31,9 @@ print("shading sections cycles/turn: lights %.0f  attrs %.0f  textures %.0f  lig
 votes = max(st2.sched_turns[6], 1)
 print("traversal lanes at a vote: idle %.1f  waiting to post %.1f" % (st2.sched_lanes[6] / votes, st2.sched_lanes[7] / votes))
 print("queue fill at a vote: ready queries %.1f  slots waiting for shading %.1f" % (st2.sched_cycles[6] / votes, st2.sched_cycles[7] / votes))
+print("regrouping: votes %d (%.2f per 64 rays), cycles per vote %.0f; parks %d with %.1f queries each; take-overs %d with %.1f queries each" % (
+    st2.sched_turns[6], st2.sched_turns[6] * 64 / rays, st2.sched_cycles[8] / votes, st2.sched_turns[8], st2.sched_lanes[8] / max(st2.sched_turns[8], 1),
+    st2.sched_turns[9], st2.sched_lanes[9] / max(st2.sched_turns[9], 1)))
 print("exchange turns: lanes that wanted a query %d, got one %d" % (st2.sched_lanes[4], st2.sched_cycles[5]))
 print("wave lifetime after the pixel queue ran dry (shading waves): %.1f %%" % (100.0 * st2.path_cycles[7] / max(st2.path_cycles[6], 1)))
 ctx.clear(); ctx.render_pass(0, spp); print("plain kernel ms", ctx.last_kernel_ms())
