@@ -501,12 +501,12 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // stack in LDS, or with almost all of it in memory).
     const uint32_t lane_bytes = S.trav_waves * 64 * 8;
     const uint32_t fit = kLdsLimit / lane_bytes, fit_deep = kLdsLimitDeep / lane_bytes;
-    ctx->regroup = crt::knob_value(getenv("CRT_REGROUP"), 0, 0, 1) != 0;
+    ctx->regroup = crt::knob_value(getenv("CRT_REGROUP"), 1, 0, 1) != 0;
     if (ctx->regroup) {
         // Regrouping kernels: a block has S.contexts query contexts, each with a stack column and 112 bytes of parked
         // state in LDS; the LDS left beside the rings decides how many stack entries a column holds (the top of the
         // stack; older entries move to device memory).
-        S.contexts = crt::knob_value(getenv("CRT_CONTEXTS"), S.trav_waves * 64, 64, kMaxContexts) & ~1u;
+        S.contexts = crt::knob_value(getenv("CRT_CONTEXTS"), S.trav_waves * 64, 64, kMaxContexts) & ~63u;
         ctx->deep = false;
         size_t fixed = 0;
         for (int variant = 0; variant < 3; variant++) {
@@ -530,6 +530,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.keep_box = crt::knob_value(getenv("CRT_KEEP_BOX"), 40, 1, 65);
     S.keep_leaf = crt::knob_value(getenv("CRT_KEEP_LEAF"), 40, 1, 65);
     S.keep_node = crt::knob_value(getenv("CRT_KEEP_NODE"), 40, 1, 65);
+    S.keep_exchange = crt::knob_value(getenv("CRT_KEEP_EXCHANGE"), 40, 1, 65);
+    S.exchange_first = crt::knob_value(getenv("CRT_EXCHANGE_FIRST"), 32, 1, 65);
     S.park_min = crt::knob_value(getenv("CRT_PARK_MIN"), 8, 1, 65);
     S.burst_max = crt::knob_value(getenv("CRT_BURST_MAX"), 16, 1, 1u << 20);
     {

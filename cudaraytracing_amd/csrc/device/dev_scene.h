@@ -127,7 +127,8 @@ struct DevScene {
     uint32_t pair_live;              // ... or while fewer than this many of the block's slots still hold a pixel
     // regrouping kernel: query contexts of a block, and how a traversal wave sticks to the operation it runs
     uint32_t contexts;               // query contexts (stack column + parked state) per block, 0: the kernel without regrouping
-    uint32_t keep_box, keep_leaf, keep_node;   // the operation runs again without a vote while this many lanes want it
+    uint32_t keep_box, keep_leaf, keep_node, keep_exchange;   // a wave stays with its operation, without a vote, while it can fill this many lanes for it
+    uint32_t exchange_first;         // an exchange (results out, new queries in) goes before any other operation once it can fill this many lanes
     uint32_t park_min;               // lanes that wait for another operation are parked once they are this many (or their lanes are needed)
     uint32_t burst_max;              // turns of one operation between two votes, at most
     uint32_t pair_below;             // a light sample's shadow query and the next segment's query start together while fewer than this many queries wait for traversal lanes

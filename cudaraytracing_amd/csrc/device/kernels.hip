@@ -455,6 +455,7 @@ struct Lane {
     uint32_t entered;               // scene node whose mesh is being traversed
     uint32_t pend;                  // LEAF: remaining leaf range; NODE: kPendExit when a mesh has to be left first
     bool shadow, mesh_hit;
+    bool more;                      // regrouping kernel: the scan has a further node to look at after the one the query is in
     // closest hit so far; normal / texture coordinates are derived from (h_*) when the query ends
     float hz;
     f3 hpos;                        // world space
@@ -492,7 +493,7 @@ constexpr uint32_t kLanePaired = 0x80000000u;        // in Lane::slot: the query
 constexpr uint32_t kPkPaired = 0x100u;               // in the HIT record's first word, beside PK_CLOSEST_DONE: a shadow query ran beside this one
 static_assert(kRecRay2 + 16 <= kSlotWords && kRecShadowEnd >= kRecPath + 28 && kRecShadowEnd < kRecRay2, "slot record layout");
 constexpr uint32_t kMaxWaves = 16;
-constexpr uint32_t kContextLog = 10, kMaxContexts = 1u << kContextLog;      // query contexts of a block (regrouping kernel)
+constexpr uint32_t kMaxContexts = 32 * 64;  // query contexts of a block (regrouping kernel): a multiple of 64, one 32-bit pool word per lane position
 constexpr uint32_t kContextBytes = 112;      // the parked part of a context: 7 x 16 bytes
 
 // The rings of a block, as indices into BlockCtl::head / tail (one array each, so that a wave reads all fills with
@@ -593,9 +594,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     __shared__ BlockCtl ctl;
     constexpr uint32_t kQLog = kDeep ? kDeepQueueLog : kQueueLog, kQSize = 1u << kQLog;      // ring of slots; slots per block <= kQSize
     constexpr uint32_t kRLog = kQLog + 1u, kRSize = 1u << kRLog, kSecond = kQSize;            // ring of ray queries: up to two per slot
-    constexpr uint32_t kCLog = kContextLog, kCSize = kRegroup ? (1u << kCLog) : 1u;           // rings of parked query contexts
     __shared__ ring_t shade_ring[2][kQSize], ray_ring[kRSize];
-    __shared__ ring_t park_ring[5][kCSize];
+    // Parked query contexts (regrouping kernel).  Context c belongs to lane position c % 64 of every traversal wave: only
+    // that lane of a wave parks it or takes it over, so stack columns and context records stay spread over the LDS
+    // banks like the lanes.  pool[q][p]: bit j set = context j * 64 + p is parked and waits for operation q.
+    __shared__ uint32_t pool[5][64];
     __shared__ uint32_t join_bits[kQSize / 32];      // bit = slot: one query of the slot's pair has ended
     __shared__ unsigned long long sect_clock[kMaxWaves], path_sections[kMaxWaves * 8], wave_clock[kMaxWaves * 2];      // counted build only
     const uint32_t tid = threadIdx.x;
@@ -613,13 +616,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         shade_ring[0][i] = 0;
         shade_ring[1][i] = (ring_t)(i < n_slots ? ((1u << kQLog) | i) : 0u);
     }
-    if (kRegroup) for (uint32_t i = tid; i < kCSize; i += CRT_BLOCK) {
-        park_ring[kQBox][i] = 0; park_ring[kQLeaf][i] = 0; park_ring[kQNode][i] = 0; park_ring[kQPost][i] = 0;
-        park_ring[kQIdle][i] = (ring_t)(i < n_ctx ? ((1u << kCLog) | i) : 0u);
-    }
+    if (kRegroup && tid < 5 * 64) pool[tid >> 6][tid & 63u] = (tid >> 6) == kQIdle ? (uint32_t)((1ull << (n_ctx >> 6)) - 1ull) : 0u;
     for (uint32_t i = tid; i < n_slots; i += CRT_BLOCK) slot_rec(i)[kRecHit] = PK_FETCH;
     if (tid < kQSize / 32) join_bits[tid] = 0;
-    if (tid < 8) { ctl.head[tid] = 0; ctl.tail[tid] = tid == kQShade1 ? n_slots : ((kRegroup && tid == kQIdle) ? n_ctx : 0u); }
+    if (tid < 8) { ctl.head[tid] = 0; ctl.tail[tid] = tid == kQShade1 ? n_slots : 0u; }
     if (tid == 0) { ctl.live = n_slots; ctl.abort = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                                       (size_t)blockIdx.x * S.stack_overflow * n_ctx;
 
         Lane L = {};
-        L.col = tid;
+        L.col = kRegroup ? (tid & 63u) : tid;
         uint32_t state = kRegroup ? (uint32_t)S_EMPTY : (uint32_t)S_IDLE;
 
         // Push / pop.  (slot * columns as a 24-bit product: the full 32-bit multiply issues at a quarter of the rate.)
@@ -756,7 +756,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // of its lanes busy instead of the few a traversal turn would have for it.
         auto walk_ended = [&]() -> uint32_t {
             L.pend = kPendExit;
-            const uint32_t next = by_mask ? first_candidate() : next_from(L.entered + 1u);
+            // (regrouping kernel: worked out when the node was entered, so that the operations inside a node need not carry the mask)
+            const uint32_t next = kRegroup ? (L.more ? 0u : node_count) : (by_mask ? first_candidate() : next_from(L.entered + 1u));
             if (next < node_count) return S_NODE;
             if (L.shadow) { L.pend = 0; return query_done(); }
             L.pk = PK_CLOSEST_DONE;
@@ -815,6 +816,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // ---- LEAF: the next two triangles of the pending leaf, one after the other (IntersectTriangle /
         // IntersectShadowTriangle, objects.cu:270-366); both records are fetched up front so that the
         // pair costs one memory round trip
+        bool leaf_hit = false;      // set by tri_test: the lane's closest hit has changed
         auto tri_test = [&](const float4 v0, const float4 v1, const float4 v2, uint32_t slot) -> bool {
             TALLY(tri_tests);
             // Same operations and order as the scalar form; independent products and sums of the two cross
@@ -844,6 +846,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const float ndot = dot(cross(edge1, edge2), dir);
             ok = ok && ((ndot < CRT_TRI_EPS) || (ndot > -CRT_TRI_EPS));
             if (ok && !L.shadow) {
+                leaf_hit = true;
                 TALLY(tri_hits);
                 L.hz = t;
                 L.mesh_hit = true;
@@ -964,6 +967,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 }
             }
             const uint32_t idx = enter_a ? L.node : L.node + 1u;
+            if (kRegroup) L.more = (by_mask ? first_candidate() : next_from(idx + 1u)) < node_count;
             const uint32_t kind = enter_a ? kind_a : kind_b;
             // the inverse matrix and the tags of the node's record; the forward matrix is fetched when the node is left
             const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
@@ -998,6 +1002,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         // ---- EXCHANGE: lanes whose query has ended write its result into their slot and queue the slot for
         // shading; they and the lanes that were idle already then take the next ready queries, whichever pixels
         // those belong to
+        bool took = false;      // op_exchange: the lane has taken a new query
         auto op_exchange = [&]() {
             const bool post = state == S_POST;
             const uint32_t my_slot = L.slot & (kQSize - 1u);
@@ -1034,6 +1039,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const bool got = queue_pop<kRLog>(&ctl.head[kQRay], &ctl.tail[kQRay], ray_ring, state == S_IDLE, 1u, kRSize, slot, &ctl.abort);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (kCount) { const uint32_t n_got = (uint32_t)__popcll(__ballot(got)); if ((tid & 63u) == 0) tally.cycles[5] += n_got; }
+            took = got;
             if (got) {
                 const uint32_t second = slot & kSecond;
                 slot &= kQSize - 1u;
@@ -1054,6 +1060,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 L.hz = CRT_BIGFLOAT; L.hpos = mk3(0, 0, 0); L.h_kind = H_NONE;
                 // no node of the scene can be hit at all: the query is over before its first box step
                 state = after_scan();
+                if (kRegroup) L.more = (by_mask ? first_candidate() : next_from(c.w + 1u)) < node_count;      // (for a query that starts inside node c.w, below)
                 // the shading wave has taken the query into the mesh of node c.w already (see write_query): d.z is the root
                 if (kFirstStepHere && (b.w & 4u)) {
                     L.entered = c.w; L.sp = 0; L.lo = 0; L.top = 0; L.mesh_hit = false;
@@ -1076,133 +1083,199 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         };
 
         // ---- query contexts (regrouping kernel) --------------------------------------------------------
-        // The parked part of a context: everything of Lane but the column, as seven 16-byte words.
-        auto ctx_store = [&]() {
-            uint4* c = reinterpret_cast<uint4*>(ctx_mem + L.col * kContextBytes);
-            const uint32_t flags = (L.slot & (kQSize - 1u)) | ((L.slot & kLanePaired) ? 0x800u : 0u) | (L.pk << 12) | (L.shadow ? 0x8000u : 0u) |
-                                   (L.mesh_hit ? 0x10000u : 0u) | (L.h_front ? 0x20000u : 0u) | (L.h_kind << 18);
-            c[0] = uint4{__float_as_uint(L.pdx.x), __float_as_uint(L.pdy.x), __float_as_uint(L.pdz.x), __float_as_uint(L.limit)};
-            c[1] = uint4{__float_as_uint(L.pdx.y), __float_as_uint(L.pdy.y), __float_as_uint(L.pdz.y), __float_as_uint(L.hz)};
-            c[2] = uint4{__float_as_uint(L.qinv.x), __float_as_uint(L.qinv.y), __float_as_uint(L.qinv.z), flags};
-            c[3] = uint4{L.node, L.cur, L.entered, L.pend};
-            c[4] = uint4{(uint32_t)L.mask, (uint32_t)(L.mask >> 32), L.sp | (L.lo << 8) | (L.top << 16), L.h_node};
-            c[5] = uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), __float_as_uint(L.h_a)};
-            c[6] = uint4{__float_as_uint(L.h_b), L.h_c, (uint32_t)L.mask_hi, (uint32_t)(L.mask_hi >> 32)};
+        // The state of a query lives in its context in LDS, as seven 16-byte words:
+        //   c0 position, limit            c1 direction, node the query is inside      c2 1 / direction, slot
+        //   c3 closest hit distance, BVH record, packed small fields, pending leaf range / exit marker
+        //   c4 candidate mask, next node to scan, (first word of the second mask word)
+        //   c5 hit: barycentrics or local point, triangle record, node and kind
+        //   c6 world position of the hit, (second word of the second mask word)
+        // A lane's registers hold a query for one turn only: every turn loads what its operation reads and stores what it
+        // may have changed, so a lane carries nothing from turn to turn but the context's number.  All lanes load (a lane
+        // without a context reads some context's words and ignores them): no branch, and the registers are defined at one
+        // place for every lane.
+        auto ctx_words = [&]() -> uint4* { return reinterpret_cast<uint4*>(ctx_mem + __umul24(L.col, kContextBytes)); };
+        auto put_small = [&]() -> uint32_t {
+            return L.sp | (L.lo << 8) | (L.top << 16) | (L.pk << 24) | (L.shadow ? 1u << 27 : 0u) | (L.more ? 1u << 28 : 0u) | (L.mesh_hit ? 1u << 29 : 0u) | (L.h_front ? 1u << 30 : 0u);
         };
-        auto ctx_load = [&]() {
-            const uint4* c = reinterpret_cast<const uint4*>(ctx_mem + L.col * kContextBytes);
-            const uint4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
-            L.pdx = f2{__uint_as_float(c0.x), __uint_as_float(c1.x)};
-            L.pdy = f2{__uint_as_float(c0.y), __uint_as_float(c1.y)};
-            L.pdz = f2{__uint_as_float(c0.z), __uint_as_float(c1.z)};
-            L.limit = __uint_as_float(c0.w); L.hz = __uint_as_float(c1.w);
-            L.qinv = mk3(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z));
-            const uint32_t flags = c2.w;
-            L.slot = (flags & (kQSize - 1u)) | ((flags & 0x800u) ? kLanePaired : 0u);
-            L.pk = (flags >> 12) & 7u; L.shadow = (flags & 0x8000u) != 0; L.mesh_hit = (flags & 0x10000u) != 0;
-            L.h_front = (flags & 0x20000u) != 0; L.h_kind = (flags >> 18) & 3u;
-            L.node = c3.x; L.cur = c3.y; L.entered = c3.z; L.pend = c3.w;
-            L.mask = (unsigned long long)c4.x | ((unsigned long long)c4.y << 32);
-            L.sp = c4.z & 255u; L.lo = (c4.z >> 8) & 255u; L.top = (c4.z >> 16) & 255u; L.h_node = c4.w;
-            L.hpos = mk3(__uint_as_float(c5.x), __uint_as_float(c5.y), __uint_as_float(c5.z)); L.h_a = __uint_as_float(c5.w);
-            L.h_b = __uint_as_float(c6.x); L.h_c = c6.y;
-            if (kWide) L.mask_hi = (unsigned long long)c6.z | ((unsigned long long)c6.w << 32);
+        auto get_c0 = [&](const uint4 c) { L.pdx.x = __uint_as_float(c.x); L.pdy.x = __uint_as_float(c.y); L.pdz.x = __uint_as_float(c.z); L.limit = __uint_as_float(c.w); };
+        auto get_c1 = [&](const uint4 c) { L.pdx.y = __uint_as_float(c.x); L.pdy.y = __uint_as_float(c.y); L.pdz.y = __uint_as_float(c.z); L.entered = c.w; };
+        auto get_c2 = [&](const uint4 c) { L.qinv = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)); L.slot = (c.w & (kQSize - 1u)) | ((c.w & kQSize) ? kLanePaired : 0u); };
+        auto get_c3 = [&](const uint4 c) {
+            L.hz = __uint_as_float(c.x); L.cur = c.y; L.pend = c.w;
+            const uint32_t w = c.z;
+            L.sp = w & 255u; L.lo = (w >> 8) & 255u; L.top = (w >> 16) & 255u; L.pk = (w >> 24) & 7u;
+            L.shadow = (w & (1u << 27)) != 0; L.more = (w & (1u << 28)) != 0; L.mesh_hit = (w & (1u << 29)) != 0; L.h_front = (w & (1u << 30)) != 0;
         };
-        // The selected lanes give their contexts up: the state goes to LDS (a free context has none) and the context's
-        // number into the ring of the operation it waits for.
+        auto get_c4 = [&](const uint4 c) { L.mask = (unsigned long long)c.x | ((unsigned long long)c.y << 32); L.node = c.z; if (kWide) L.mask_hi = (L.mask_hi & 0xffffffff00000000ull) | c.w; };
+        auto get_c5 = [&](const uint4 c) { L.h_a = __uint_as_float(c.x); L.h_b = __uint_as_float(c.y); L.h_c = c.z; L.h_node = c.w & 0x0fffffffu; L.h_kind = c.w >> 28; };
+        auto get_c6 = [&](const uint4 c) { L.hpos = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)); if (kWide) L.mask_hi = (L.mask_hi & 0xffffffffull) | ((unsigned long long)c.w << 32); };
+        auto put_c0 = [&]() -> uint4 { return uint4{__float_as_uint(L.pdx.x), __float_as_uint(L.pdy.x), __float_as_uint(L.pdz.x), __float_as_uint(L.limit)}; };
+        auto put_c1 = [&]() -> uint4 { return uint4{__float_as_uint(L.pdx.y), __float_as_uint(L.pdy.y), __float_as_uint(L.pdz.y), L.entered}; };
+        auto put_c2 = [&]() -> uint4 { return uint4{__float_as_uint(L.qinv.x), __float_as_uint(L.qinv.y), __float_as_uint(L.qinv.z), (L.slot & (kQSize - 1u)) | ((L.slot & kLanePaired) ? kQSize : 0u)}; };
+        auto put_c3 = [&]() -> uint4 { return uint4{__float_as_uint(L.hz), L.cur, put_small(), L.pend}; };
+        auto put_c4 = [&]() -> uint4 { return uint4{(uint32_t)L.mask, (uint32_t)(L.mask >> 32), L.node, kWide ? (uint32_t)L.mask_hi : 0u}; };
+        auto put_c5 = [&]() -> uint4 { return uint4{__float_as_uint(L.h_a), __float_as_uint(L.h_b), L.h_c, (L.h_node & 0x0fffffffu) | (L.h_kind << 28)}; };
+        auto put_c6 = [&]() -> uint4 { return uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), kWide ? (uint32_t)(L.mask_hi >> 32) : 0u}; };
+
+        // The selected lanes give their contexts up: the context's bit goes into the pool of the operation it waits for
+        // (its state is in LDS already).
+        const uint32_t lane = tid & 63u;
         auto park = [&](bool sel) {
             if (kCount) { tally.turns[8]++; tally.lanes[8] += sel; }
-            if (sel && state != S_IDLE) ctx_store();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#pragma unroll
-            for (uint32_t q = kQBox; q <= kQIdle; q++) queue_push<kCLog>(&ctl.tail[q], park_ring[q], sel && state == q, L.col);
-            if (sel) state = S_EMPTY;
+            if (sel) {
+                __hip_atomic_fetch_or(&pool[state][lane], 1u << (L.col >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                state = S_EMPTY;
+            }
         };
-        // Empty lanes (at most `most` of them) take contexts that wait for operation q.
-        auto unpark = [&](uint32_t q, uint32_t most) {
-            const unsigned long long empty = __ballot(state == S_EMPTY);
-            const bool want = state == S_EMPTY && lane_rank(empty) < most;
-            uint32_t col = 0;
-            const bool got = queue_pop<kCLog>(&ctl.head[q], &ctl.tail[q], park_ring[q], want, 1u, n_ctx, col, &ctl.abort);
+        // Lanes with `want` (empty ones) take a context of their lane position that waits for operation q, the first
+        // `most` of the lanes that have one to take.
+        auto unpark = [&](uint32_t q, bool want, uint32_t most) {
+            uint32_t m = want ? lds_ld(&pool[q][lane]) : 0u;
+            if (most < 64u && lane_rank(__ballot(m != 0)) >= most) m = 0;
+            bool got = false;
+            uint32_t j = 0;
+#pragma unroll 1
+            for (int attempt = 0; attempt < 2 && __ballot(m != 0 && !got) != 0; attempt++) {
+                if (m != 0 && !got) {
+                    j = (uint32_t)__ffs((int)m) - 1u;
+                    const uint32_t old = __hip_atomic_fetch_and(&pool[q][lane], ~(1u << j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    got = (old >> j) & 1u;
+                    m = old & ~(1u << j);      // another wave took it first: what else was there
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (kCount) { tally.turns[9]++; tally.lanes[9] += got; }
-            if (got) {
-                L.col = col;
-                if (q != kQIdle) ctx_load();
-                state = q;
-            }
+            if (got) { L.col = (j << 6) | lane; state = q; }
         };
 
         // ---- the scheduler of a traversal wave ------------------------------------------------------
         if constexpr (kRegroup) {
-            // A wave runs ONE operation with as many of its lanes as it can fill.  At every vote it looks at what its own
-            // lanes wait for and at what is parked, picks the operation with the most queries within reach, parks the
-            // lanes that wait for something else, takes parked queries of its pick into the lanes that are free, and
-            // runs the operation until too few of its lanes want another turn.
-            const uint32_t lane = tid & 63u;
+            // A wave runs ONE operation with as many of its lanes as it can fill: the lanes that wait for something
+            // else park their queries, free lanes take parked queries that wait for the wave's operation.  The wave stays
+            // with its operation while enough lanes can be filled; then it votes: the operation with the most
+            // queries within reach of its lanes is next.
+            uint32_t mode = S_POST;
+            uint32_t fruitless = 0;      // votes in a row after which no lane of the wave moved
+            // turns of one traversal operation, until too few lanes can be filled for it
+            auto run = [&](auto op_tag, uint32_t keep) {
+                constexpr uint32_t kOp = decltype(op_tag)::value;
+                unsigned long long t_mark = 0;
+                if (kCount) t_mark = __builtin_amdgcn_s_memtime();
+                for (uint32_t turns = 0;;) {
+                    const bool other = state != S_EMPTY && state != kOp;
+                    if (__ballot(other) != 0) park(other);
+                    unpark(kOp, state == S_EMPTY, 64u);
+                    const bool active = state == kOp;
+                    if (__ballot(active) == 0) break;
+                    fruitless = 0;
+                    if (kCount) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tally.cycles[8] += t - t_mark; t_mark = t; tally.turns[kOp]++; tally.lanes[kOp] += active; }
+                    uint4* const c = ctx_words();
+                    if (kOp == S_BOX) {
+                        const uint4 c0 = c[0], c2 = c[2], c3 = c[3];
+                        get_c0(c0); get_c2(c2); get_c3(c3);
+                        if (active) { state = op_box(); c[3] = put_c3(); }
+                    } else if (kOp == S_LEAF) {
+                        const uint4 c0 = c[0], c1 = c[1], c3 = c[3];
+                        get_c0(c0); get_c1(c1); get_c3(c3);
+                        if (active) {
+                            leaf_hit = false;
+                            state = op_leaf();
+                            c[3] = put_c3();
+                            if (leaf_hit) c[5] = put_c5();
+                        }
+                    } else {
+                        const uint4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
+                        get_c0(c0); get_c1(c1); get_c2(c2); get_c3(c3); get_c4(c4); get_c5(c5); get_c6(c6);
+                        if (active) {
+                            state = op_node();
+                            c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6();
+                        }
+                    }
+                    if (kCount) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tally.cycles[kOp] += t - t_mark; t_mark = t; }
+                    // another turn without a vote while enough lanes can be filled
+                    const uint32_t again = (uint32_t)__popcll(__ballot(state == kOp || lds_ld(&pool[kOp][lane]) != 0));
+                    if (again < keep || ++turns >= S.burst_max) break;
+                }
+                if (kCount) tally.cycles[8] += __builtin_amdgcn_s_memtime() - t_mark;
+            };
             for (;;) {
                 unsigned long long t_vote = 0;
                 if (kCount) t_vote = __builtin_amdgcn_s_memtime();
-                const uint32_t nB = (uint32_t)__popcll(__ballot(state == S_BOX)), nL = (uint32_t)__popcll(__ballot(state == S_LEAF));
-                const uint32_t nN = (uint32_t)__popcll(__ballot(state == S_NODE)), nP = (uint32_t)__popcll(__ballot(state == S_POST));
-                const uint32_t nI = (uint32_t)__popcll(__ballot(state == S_IDLE));
-                const uint32_t nE = 64u - nB - nL - nN - nP - nI;
-                // fill of the five context rings and of the ray ring: lane q reads ring q
-                uint32_t fill = 0;
-                if (lane < 6u) { const uint32_t h = lds_ld(&ctl.head[lane]); fill = lds_ld(&ctl.tail[lane]) - h; }      // (head first: never negative)
-                const uint32_t fB = __builtin_amdgcn_readlane(fill, kQBox), fL = __builtin_amdgcn_readlane(fill, kQLeaf);
-                const uint32_t fN = __builtin_amdgcn_readlane(fill, kQNode), fP = __builtin_amdgcn_readlane(fill, kQPost);
-                const uint32_t fI = __builtin_amdgcn_readlane(fill, kQIdle), fR = __builtin_amdgcn_readlane(fill, kQRay);
+                // A wave that keeps voting without moving any query has met a case the protocol does not cover: it
+                // reports the error and leaves, as does every wave once one has.
+                bool give_up = false;
+                if ((++fruitless & 255u) == 0) {
+                    if (lds_ld(&ctl.abort) != 0) break;
+                    give_up = fruitless > (1u << 20);
+                }
+                // lanes this wave could run each operation with: its own that wait for it, and parked ones of every other lane's position
+                const uint32_t pB = lds_ld(&pool[kQBox][lane]), pL = lds_ld(&pool[kQLeaf][lane]), pN = lds_ld(&pool[kQNode][lane]);
+                const uint32_t pP = lds_ld(&pool[kQPost][lane]), pI = lds_ld(&pool[kQIdle][lane]);
+                const uint32_t h_ray = lds_ld(&ctl.head[kQRay]), fR = lds_ld(&ctl.tail[kQRay]) - h_ray;
+                const uint32_t cB = (uint32_t)__popcll(__ballot(state == S_BOX || pB != 0)), cL = (uint32_t)__popcll(__ballot(state == S_LEAF || pL != 0));
+                const uint32_t cN = (uint32_t)__popcll(__ballot(state == S_NODE || pN != 0));
+                const bool can_post = state == S_POST || pP != 0;
+                const uint32_t posts = (uint32_t)__popcll(__ballot(can_post));
+                const uint32_t idles = (uint32_t)__popcll(__ballot(!can_post && (state == S_IDLE || pI != 0)));
+                // an exchange serves the lanes with a result to post (they take a new query like the idle ones) and as many
+                // free contexts as the ray ring has queries for
+                const uint32_t takers = fR > posts ? (fR - posts < idles ? fR - posts : idles) : 0u;
+                const uint32_t cX = posts + takers;
                 if (kCount) {      // census at every vote
                     tally.turns[6]++; tally.lanes[6] += (state == S_IDLE || state == S_EMPTY); tally.lanes[7] += state == S_POST;
                     if (lane == 0) { tally.cycles[6] += fR; tally.cycles[7] += (lds_ld(&ctl.tail[kQShade0]) - lds_ld(&ctl.head[kQShade0])) + (lds_ld(&ctl.tail[kQShade1]) - lds_ld(&ctl.head[kQShade1])); }
                 }
-                // queries within reach per operation.  An exchange serves lanes with a result to post (they then take a
-                // new query like the idle ones) and as many free contexts as the ray ring has queries for.
-                const uint32_t posts = nP + fP;
-                const uint32_t idles = nI + fI;
-                const uint32_t takers = fR > posts ? (fR - posts < idles ? fR - posts : idles) : 0u;
-                const uint32_t dB = nB + fB, dL = nL + fL, dN = nN + fN, dX = posts + takers;
-                auto capped = [](uint32_t d) -> uint32_t { return d < 64u ? d : 64u; };
-                uint32_t best = S_POST, best_d = dX;
-                auto consider = [&](uint32_t op, uint32_t d) { if (capped(d) > capped(best_d) || (capped(d) == capped(best_d) && d > best_d)) { best = op; best_d = d; } };
-                consider(S_NODE, dN); consider(S_LEAF, dL); consider(S_BOX, dB);
-                if (best_d == 0) {
-                    // nothing within reach: no query anywhere in the block that a traversal lane could move
-                    if (!idle_wait()) break;
-                    continue;
+                if (give_up) {
+                    lds_st(&ctl.abort, 1u);
+                    if (lane == 0) atomicAdd(&stats->errors, 1ull);
+                    break;
+                }
+                const uint32_t c_mode = mode == S_BOX ? cB : (mode == S_LEAF ? cL : (mode == S_NODE ? cN : cX));
+                const uint32_t keep_mode = mode == S_BOX ? S.keep_box : (mode == S_LEAF ? S.keep_leaf : (mode == S_NODE ? S.keep_node : S.keep_exchange));
+                if (cX >= S.exchange_first) mode = S_POST;      // queries in, results out: before anything else once there are enough of them
+                else if (c_mode < keep_mode) {
+                    uint32_t best = S_POST, best_c = cX;
+                    if (cN > best_c) { best = S_NODE; best_c = cN; }
+                    if (cL > best_c) { best = S_LEAF; best_c = cL; }
+                    if (cB > best_c) { best = S_BOX; best_c = cB; }
+                    if (best_c == 0) {
+                        // nothing within reach: no query anywhere in the block that this wave's lanes could move
+                        fruitless = 0;
+                        if (!idle_wait()) break;
+                        continue;
+                    }
+                    mode = best;
                 }
                 idle_polls = 0;
-                // lanes that wait for something else go to the rings when they are many, or when their lanes are needed
-                const bool mine = best == S_POST ? (state == S_POST || state == S_IDLE) : state == best;
-                const bool other = state != S_EMPTY && !mine;
-                const uint32_t n_mine = (uint32_t)__popcll(__ballot(mine)), n_other = 64u - nE - n_mine;
-                const uint32_t reach = capped(best_d) - n_mine;
-                if (n_other != 0 && (n_other >= S.park_min || reach > nE)) park(other);
-                unsigned long long t_start = 0;
-                if (best == S_POST) {
-                    if (fP) unpark(kQPost, 64u);
-                    // free contexts only for the queries that the lanes at hand cannot take
+                if (kCount) tally.cycles[8] += __builtin_amdgcn_s_memtime() - t_vote;
+                if (mode == S_BOX) run(std::integral_constant<uint32_t, S_BOX>{}, S.keep_box);
+                else if (mode == S_LEAF) run(std::integral_constant<uint32_t, S_LEAF>{}, S.keep_leaf);
+                else if (mode == S_NODE) run(std::integral_constant<uint32_t, S_NODE>{}, S.keep_node);
+                else {
+                    // lanes that wait for a traversal operation park, and so do free contexts beyond the queries the ray ring
+                    // has for them (a lane that holds one could not take a result to post); free lanes take results to
+                    // post, then free contexts for the queries that the lanes at hand cannot take
+                    unsigned long long t_start = 0;
+                    if (kCount) t_start = __builtin_amdgcn_s_memtime();
+                    const bool leave = state <= S_NODE || (state == S_IDLE && lane_rank(__ballot(state == S_IDLE)) >= fR);
+                    if (__ballot(leave) != 0) park(leave);
+                    unpark(kQPost, state == S_EMPTY, 64u);
                     const uint32_t at_hand = (uint32_t)__popcll(__ballot(state == S_POST || state == S_IDLE));
-                    if (fI && fR > at_hand) unpark(kQIdle, fR - at_hand);
-                    if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.cycles[8] += t_start - t_vote; tally.turns[4]++; tally.lanes[4] += (state == S_POST || state == S_IDLE); }
+                    if (fR > at_hand) unpark(kQIdle, state == S_EMPTY, fR - at_hand);
+                    if (kCount) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tally.cycles[8] += t - t_start; t_start = t; tally.turns[4]++; tally.lanes[4] += (state == S_POST || state == S_IDLE); }
+                    const unsigned long long waiting = __ballot(state == S_IDLE);
+                    if (__ballot(state == S_POST) != 0) fruitless = 0;
+                    uint4* const c = ctx_words();
+                    {
+                        const uint4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c5 = c[5], c6 = c[6];
+                        get_c0(c0); get_c1(c1); get_c2(c2); get_c3(c3); get_c5(c5); get_c6(c6);
+                    }
                     op_exchange();
+                    if (took) { c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6(); }
+                    if (__ballot(state == S_IDLE) != waiting) fruitless = 0;
                     if (kCount) tally.cycles[4] += __builtin_amdgcn_s_memtime() - t_start;
-                    continue;
                 }
-                if (reach) unpark(best, 64u);
-                if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.cycles[8] += t_start - t_vote; }
-                const uint32_t keep = best == S_BOX ? S.keep_box : (best == S_LEAF ? S.keep_leaf : S.keep_node);
-                uint32_t n_now = (uint32_t)__popcll(__ballot(state == best)), n_first = n_now, turns = 0;
-                // the operation runs again while enough lanes want it, or while nobody has left it (then a vote would come out the same)
-                while (n_now != 0 && (turns == 0 || n_now >= keep || n_now == n_first) && turns < S.burst_max) {
-                    if (best == S_BOX) { if (kCount) { tally.turns[0]++; tally.lanes[0] += state == S_BOX; } if (state == S_BOX) state = op_box(); }
-                    else if (best == S_LEAF) { if (kCount) { tally.turns[1]++; tally.lanes[1] += state == S_LEAF; } if (state == S_LEAF) state = op_leaf(); }
-                    else { if (kCount) { tally.turns[2]++; tally.lanes[2] += state == S_NODE; } if (state == S_NODE) state = op_node(); }
-                    n_now = (uint32_t)__popcll(__ballot(state == best));
-                    turns++;
-                }
-                if (kCount) tally.cycles[best] += __builtin_amdgcn_s_memtime() - t_start;
             }
         } else
         for (;;) {
