@@ -532,6 +532,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.keep_node = crt::knob_value(getenv("CRT_KEEP_NODE"), 40, 1, 65);
     S.keep_exchange = crt::knob_value(getenv("CRT_KEEP_EXCHANGE"), 40, 1, 65);
     S.exchange_first = crt::knob_value(getenv("CRT_EXCHANGE_FIRST"), 32, 1, 65);
+    S.run_min = crt::knob_value(getenv("CRT_RUN_MIN"), 1, 1, 65);
+    S.run_patience = crt::knob_value(getenv("CRT_RUN_PATIENCE"), 8, 0, 1u << 20);
     S.park_min = crt::knob_value(getenv("CRT_PARK_MIN"), 8, 1, 65);
     S.burst_max = crt::knob_value(getenv("CRT_BURST_MAX"), 16, 1, 1u << 20);
     {

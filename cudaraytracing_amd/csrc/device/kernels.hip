@@ -1124,29 +1124,34 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (kCount) { tally.turns[8]++; tally.lanes[8] += sel; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (sel) {
-                __hip_atomic_fetch_or(&pool[state][lane], 1u << (L.col >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&pool[state][L.col & 63u], 1u << (L.col >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 state = S_EMPTY;
             }
         };
-        // Lanes with `want` (empty ones) take a context of their lane position that waits for operation q, the first
-        // `most` of the lanes that have one to take.
+        // What lane position p may take: contexts of position p and of position p ^ 32.  The two positions map to the same
+        // LDS banks and lie in different halves of the wave, which the LDS serves in different cycles: a lane that works
+        // on a context of its partner position conflicts with nobody.
+        auto parked = [&](uint32_t q, uint32_t& own, uint32_t& partner) {
+            own = lds_ld(&pool[q][lane]); partner = lds_ld(&pool[q][lane ^ 32u]);
+        };
+        // Lanes with `want` (empty ones) take a context that waits for operation q, the first `most` of the lanes that
+        // have one to take.  One attempt: a lane that loses its pick to another wave stays empty for this turn.
         auto unpark = [&](uint32_t q, bool want, uint32_t most) {
-            uint32_t m = want ? lds_ld(&pool[q][lane]) : 0u;
+            uint32_t own, partner;
+            parked(q, own, partner);
+            const uint32_t pos = own ? lane : lane ^ 32u;
+            uint32_t m = want ? (own ? own : partner) : 0u;
             if (most < 64u && lane_rank(__ballot(m != 0)) >= most) m = 0;
             bool got = false;
             uint32_t j = 0;
-#pragma unroll 1
-            for (int attempt = 0; attempt < 2 && __ballot(m != 0 && !got) != 0; attempt++) {
-                if (m != 0 && !got) {
-                    j = (uint32_t)__ffs((int)m) - 1u;
-                    const uint32_t old = __hip_atomic_fetch_and(&pool[q][lane], ~(1u << j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    got = (old >> j) & 1u;
-                    m = old & ~(1u << j);      // another wave took it first: what else was there
-                }
+            if (m != 0) {
+                j = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t old = __hip_atomic_fetch_and(&pool[q][pos], ~(1u << j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                got = (old >> j) & 1u;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (kCount) { tally.turns[9]++; tally.lanes[9] += got; }
-            if (got) { L.col = (j << 6) | lane; state = q; }
+            if (got) { L.col = (j << 6) | pos; state = q; }
         };
 
         // ---- the scheduler of a traversal wave ------------------------------------------------------
@@ -1157,6 +1162,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // queries within reach of its lanes is next.
             uint32_t mode = S_POST;
             uint32_t fruitless = 0;      // votes in a row after which no lane of the wave moved
+            uint32_t waited = 0;         // votes in a row at which the wave chose to wait for more queries
             // turns of one traversal operation, until too few lanes can be filled for it
             auto run = [&](auto op_tag, uint32_t keep) {
                 constexpr uint32_t kOp = decltype(op_tag)::value;
@@ -1194,7 +1200,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     }
                     if (kCount) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tally.cycles[kOp] += t - t_mark; t_mark = t; }
                     // another turn without a vote while enough lanes can be filled
-                    const uint32_t again = (uint32_t)__popcll(__ballot(state == kOp || lds_ld(&pool[kOp][lane]) != 0));
+                    uint32_t own, partner;
+                    parked(kOp, own, partner);
+                    const uint32_t again = (uint32_t)__popcll(__ballot(state == kOp || (own | partner) != 0));
                     if (again < keep || ++turns >= S.burst_max) break;
                 }
                 if (kCount) tally.cycles[8] += __builtin_amdgcn_s_memtime() - t_mark;
@@ -1210,8 +1218,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     give_up = fruitless > (1u << 20);
                 }
                 // lanes this wave could run each operation with: its own that wait for it, and parked ones of every other lane's position
-                const uint32_t pB = lds_ld(&pool[kQBox][lane]), pL = lds_ld(&pool[kQLeaf][lane]), pN = lds_ld(&pool[kQNode][lane]);
-                const uint32_t pP = lds_ld(&pool[kQPost][lane]), pI = lds_ld(&pool[kQIdle][lane]);
+                uint32_t pB, pL, pN, pP, pI;
+                { uint32_t o, q; parked(kQBox, o, q); pB = o | q; parked(kQLeaf, o, q); pL = o | q; parked(kQNode, o, q); pN = o | q; parked(kQPost, o, q); pP = o | q; parked(kQIdle, o, q); pI = o | q; }
                 const uint32_t h_ray = lds_ld(&ctl.head[kQRay]), fR = lds_ld(&ctl.tail[kQRay]) - h_ray;
                 const uint32_t cB = (uint32_t)__popcll(__ballot(state == S_BOX || pB != 0)), cL = (uint32_t)__popcll(__ballot(state == S_LEAF || pL != 0));
                 const uint32_t cN = (uint32_t)__popcll(__ballot(state == S_NODE || pN != 0));
@@ -1245,8 +1253,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                         if (!idle_wait()) break;
                         continue;
                     }
+                    // few queries within reach, and not for long yet: let them gather (the waves that run meanwhile run fuller)
+                    if (best_c < S.run_min && waited < S.run_patience) { waited++; fruitless = 0; __builtin_amdgcn_s_sleep(2); continue; }
                     mode = best;
                 }
+                waited = 0;
                 idle_polls = 0;
                 if (kCount) tally.cycles[8] += __builtin_amdgcn_s_memtime() - t_vote;
                 if (mode == S_BOX) run(std::integral_constant<uint32_t, S_BOX>{}, S.keep_box);
