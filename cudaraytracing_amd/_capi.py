@@ -99,6 +99,7 @@ _PROTOS = {
     "crt_png_write_rgb8": (C.c_int, [C.c_char_p, _VP, C.c_uint32, C.c_uint32]),
     "crt_png_read_rgb8": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "crt_free": (None, [_VP]),
+    "crt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "crt_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "crt_destroy": (None, [_VP]),
     "crt_last_error": (C.c_char_p, [_VP]),

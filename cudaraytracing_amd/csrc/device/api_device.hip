@@ -43,7 +43,6 @@ struct crt_ctx {
     uint64_t launches = 0;                          // launches recorded so far
     uint64_t reported = 0;                          // launches already handed out by crt_kernel_times
     unsigned char* scratch = nullptr;          // this device's copy of the static workspace (crt_render_pass_noalloc)
-    std::map<int, std::vector<uint32_t>> host_jumps;   // pass -> jump matrix on the host, for the call that allocates nothing
     int num_cus = 0;
     size_t lds_bytes = 0;
     int blocks_per_cu = 0, blocks_per_cu_counted = 0;
@@ -54,7 +53,9 @@ struct crt_ctx {
 // library runs on holds its own copy at its own address until the process ends; host code never uses the array's
 // name as an address, only the pointer hipGetSymbolAddress returned for the device in use (scratch_for_device).
 constexpr size_t kScratchBytes = 32u << 20;
-constexpr size_t kScratchQueueOff = 0, kScratchJumpOff = 256, kScratchStateOff = 4096;
+constexpr int kScratchPasses = 64;      // sequence-jump matrices of passes 1 .. kScratchPasses - 1 are kept in the workspace
+constexpr size_t kJumpBytes = 160 * 5 * 4;
+constexpr size_t kScratchQueueOff = 0, kScratchJumpOff = 256, kScratchStateOff = (kScratchJumpOff + kScratchPasses * kJumpBytes + 4095) / 4096 * 4096;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 namespace {
@@ -70,22 +71,20 @@ namespace {
 
 int fail(crt_ctx* ctx, int code, const std::string& msg) { ctx->error = msg; return code; }
 
-// Device address of `scratch` on the current device, looked up once per device.
-hipError_t scratch_for_device(int device, unsigned char** out) {
-    static std::mutex lock;
-    static std::map<int, unsigned char*> known;
-    std::lock_guard<std::mutex> guard(lock);
-    auto it = known.find(device);
-    if (it == known.end()) {
-        void* p = nullptr;
-        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
-        if (e != hipSuccess) return e;
-        if (!p) return hipErrorInvalidSymbol;
-        it = known.emplace(device, (unsigned char*)p).first;
-    }
-    *out = it->second;
-    return hipSuccess;
+// A trace kernel whose hand-off protocol failed has counted its waves that gave up in DevStats::errors and left
+// the image incomplete: every call that hands results to the caller looks here first.  (Work queued on other
+// streams than the default one is the caller's to wait for, as for the copy itself.)
+int check_kernel_errors(crt_ctx* ctx) {
+    unsigned long long errors = 0;
+    HIP_TRY(ctx, hipMemcpy(&errors, &ctx->stats->errors, sizeof errors, hipMemcpyDeviceToHost));
+    if (errors) return fail(ctx, CRT_E_HIP, "the trace kernel reported " + std::to_string(errors) + " queue protocol error(s): the image is incomplete");
+    return CRT_OK;
 }
+
+// Device address of `scratch` on the current device, looked up once per device.  The first look-up on a device also
+// fills the table of sequence-jump matrices (the same for every context and every scene), so that the call that
+// allocates nothing copies nothing either.
+hipError_t scratch_for_device(int device, unsigned char** out);
 
 void free_scene(crt_ctx* ctx) {
     for (void* p : ctx->allocs) (void)hipFree(p);
@@ -173,6 +172,35 @@ int get_jump(crt_ctx* ctx, int pass, const uint32_t** dev) {
     return CRT_OK;
 }
 
+hipError_t scratch_for_device(int device, unsigned char** out) {
+    static std::mutex lock;
+    static std::map<int, unsigned char*> known;
+    std::lock_guard<std::mutex> guard(lock);
+    auto it = known.find(device);
+    if (it == known.end()) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        static std::vector<uint32_t> table;      // passes 1 .. kScratchPasses - 1, computed once per process
+        if (table.empty()) {
+            table.resize((size_t)kScratchPasses * 800, 0u);
+            for (int pass = 1; pass < kScratchPasses; pass++) {
+                BitMat m;
+                jump_for_pass((unsigned)pass, m);
+                memcpy(&table[(size_t)pass * 800], m.row, kJumpBytes);
+            }
+        }
+        e = hipMemcpy((unsigned char*)p + kScratchJumpOff, table.data(), table.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        e = hipMemset((unsigned char*)p + kScratchQueueOff, 0, 256);      // the pixel queue's counter: every launch leaves it at zero again
+        if (e != hipSuccess) return e;
+        it = known.emplace(device, (unsigned char*)p).first;
+    }
+    *out = it->second;
+    return hipSuccess;
+}
+
 int validate_desc(crt_ctx* ctx, const crt_scene_desc* d) {
     if (!d) return fail(ctx, CRT_E_INVALID, "null scene");
     if (d->camera.width == 0 || d->camera.height == 0) return fail(ctx, CRT_E_INVALID, "image size is zero");
@@ -258,6 +286,7 @@ void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_r
     P.total_items = owned * P.items_per_strip;
     P.tile_order = nullptr;
     P.tile_cost = nullptr;
+    P.self_reset = 0;
     ctx->order_valid = false;                  // costs of another partition say nothing about this one
 }
 
@@ -337,6 +366,14 @@ void crt_destroy(crt_ctx* ctx) {
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
     }
     delete ctx;
+}
+
+int crt_device_count(int* count) {
+    if (!count) return CRT_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { crt::set_host_error("no HIP device available"); *count = 0; return CRT_E_HIP; }
+    *count = n;
+    return CRT_OK;
 }
 
 const char* crt_last_error(const crt_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
@@ -501,7 +538,9 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // stack in LDS, or with almost all of it in memory).
     const uint32_t lane_bytes = S.trav_waves * 64 * 8;
     const uint32_t fit = kLdsLimit / lane_bytes, fit_deep = kLdsLimitDeep / lane_bytes;
-    ctx->regroup = crt::knob_value(getenv("CRT_REGROUP"), 1, 0, 1) != 0;
+    // Trees that the plain LDS stack holds run the regrouping kernels; a tree too deep for it is bound by memory
+    // latency, and there the kernels for deep trees (more queries in flight, 23 stack entries in LDS) are faster.
+    ctx->regroup = crt::knob_value(getenv("CRT_REGROUP"), stack_total <= fit ? 1 : 0, 0, 1) != 0;
     if (ctx->regroup) {
         // Regrouping kernels: a block has S.contexts query contexts, each with a stack column and 112 bytes of parked
         // state in LDS; the LDS left beside the rings decides how many stack entries a column holds (the top of the
@@ -532,9 +571,6 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.keep_node = crt::knob_value(getenv("CRT_KEEP_NODE"), 40, 1, 65);
     S.keep_exchange = crt::knob_value(getenv("CRT_KEEP_EXCHANGE"), 40, 1, 65);
     S.exchange_first = crt::knob_value(getenv("CRT_EXCHANGE_FIRST"), 32, 1, 65);
-    S.run_min = crt::knob_value(getenv("CRT_RUN_MIN"), 1, 1, 65);
-    S.run_patience = crt::knob_value(getenv("CRT_RUN_PATIENCE"), 8, 0, 1u << 20);
-    S.park_min = crt::knob_value(getenv("CRT_PARK_MIN"), 8, 1, 65);
     S.burst_max = crt::knob_value(getenv("CRT_BURST_MAX"), 16, 1, 1u << 20);
     {
         // Drift bound of the scan's candidate mask.  One round trip through node j maps p to fl(tm * fl(itm * p)): its
@@ -623,6 +659,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.serve_priority = crt::knob_value(getenv("CRT_SERVE_PRIORITY"), 1, 0, 1);
     S.pair_live = crt::knob_value(getenv("CRT_PAIR_LIVE"), ctx->deep ? (1u << 20) : S.trav_waves * 80, 0, 1u << 20);
     S.pair_below = crt::knob_value(getenv("CRT_PAIR_BELOW"), 0, 0, 1u << 20);
+    S.fault_inject = crt::knob_value(getenv("CRT_FAULT_INJECT"), 0, 0, 1);      // tests only: the kernel loses one query, so that its watchdog has something to find
     S.watchdog_ticks = 100000000ull * crt::knob_value(getenv("CRT_WATCHDOG_SECONDS"), 30, 1, 3600);
     ctx->interleave = crt::knob_value(getenv("CRT_TILE_INTERLEAVE"), 0, 0, 1) != 0;
     { const char* e = getenv("CRT_NO_BALANCE"); ctx->no_balance = e && atoi(e) != 0; }
@@ -736,7 +773,10 @@ static int render_impl(crt_ctx* ctx, int pass_id, int samples, hipStream_t strea
         HIP_TRY(ctx, hipGetLastError());
         ctx->order_valid = true;
     }
-    if (!async) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (!async) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        return check_kernel_errors(ctx);
+    }
     return CRT_OK;
 }
 
@@ -765,26 +805,23 @@ int crt_render_pass_noalloc(crt_ctx* ctx, int pass_id, int samples, void* stream
     if (grid > blocks_fit) grid = (uint32_t)blocks_fit;
     unsigned char* ws = ctx->scratch;
     const uint32_t* jump = nullptr;
-    if (pass_id > 0) {
-        auto it = ctx->host_jumps.find(pass_id);
-        if (it == ctx->host_jumps.end()) {
-            BitMat m;
-            jump_for_pass((unsigned)pass_id, m);
-            it = ctx->host_jumps.emplace(pass_id, std::vector<uint32_t>(&m.row[0][0], &m.row[0][0] + 800)).first;
-        }
-        HIP_TRY(ctx, hipMemcpyAsync(ws + kScratchJumpOff, it->second.data(), 3200, hipMemcpyHostToDevice, stream));
-        jump = (const uint32_t*)(ws + kScratchJumpOff);
-    }
-    // the workspace keeps what the previous call left: the queue counter has to start at zero (the path state is
-    // written before it is read, pixel by pixel)
-    HIP_TRY(ctx, hipMemsetAsync(ws + kScratchQueueOff, 0, 256, stream));
+    if (pass_id >= kScratchPasses)
+        return fail(ctx, CRT_E_LIMIT, "pass_id " + std::to_string(pass_id) + " is beyond the " + std::to_string(kScratchPasses) + " passes whose sequence jumps the static workspace holds");
+    if (pass_id > 0) jump = (const uint32_t*)(ws + kScratchJumpOff + (size_t)pass_id * kJumpBytes);
+    // The workspace keeps what the previous call left.  The path state is written before it is read, pixel by pixel; the
+    // pixel queue's counter has to start at zero, and every launch leaves it there for the next one (a memset node
+    // between two kernels of a recorded graph was seen to run before the first kernel had finished).
     DevPartition P = ctx->P;
     P.tile_cost = nullptr; P.tile_order = nullptr;      // storage order: the balance tables belong to crt_render_pass
+    P.self_reset = 1;
     uint32_t* queue = (uint32_t*)(ws + kScratchQueueOff);
     uint32_t* state = (uint32_t*)(ws + kScratchStateOff);
     launch_trace(ctx, false, false, grid, stream, P, samples, jump, queue, nullptr, nullptr, nullptr, state);
     HIP_TRY(ctx, hipGetLastError());
-    if (!async) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (!async) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        return check_kernel_errors(ctx);
+    }
     return CRT_OK;
 }
 
@@ -860,7 +897,7 @@ int crt_read_image(crt_ctx* ctx, uint8_t* rgb_host) {
     if (!ctx->have_scene) return fail(ctx, CRT_E_NOSCENE, "no scene uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpy(rgb_host, ctx->rgb8, (size_t)ctx->S.width * ctx->S.height * 3, hipMemcpyDeviceToHost));
-    return CRT_OK;
+    return check_kernel_errors(ctx);
 }
 
 int crt_read_accumulators(crt_ctx* ctx, float* results, float* normals, float* albedos) {
@@ -871,7 +908,7 @@ int crt_read_accumulators(crt_ctx* ctx, float* results, float* normals, float* a
     if (results) HIP_TRY(ctx, hipMemcpy(results, ctx->S.results, bytes, hipMemcpyDeviceToHost));
     if (normals) HIP_TRY(ctx, hipMemcpy(normals, ctx->S.normals, bytes, hipMemcpyDeviceToHost));
     if (albedos) HIP_TRY(ctx, hipMemcpy(albedos, ctx->S.albedos, bytes, hipMemcpyDeviceToHost));
-    return CRT_OK;
+    return check_kernel_errors(ctx);
 }
 
 int crt_device_buffers(crt_ctx* ctx, void** results, void** normals, void** albedos, void** rgb8) {
@@ -970,7 +1007,8 @@ int crt_rng_selftest(crt_ctx* ctx, const uint32_t* seeds, const uint32_t* subseq
 }
 
 int crt_math_selftest(crt_ctx* ctx, int fn, const float* x, const float* y, uint32_t n, float* out) {
-    if (!ctx || !x || !out || n == 0 || fn < 0 || (fn > 8 && fn != 100)) return CRT_E_INVALID;
+    if (!ctx || !out || fn < 0 || (fn > 8 && fn != 100)) return CRT_E_INVALID;
+    if (fn != 100 && (!x || n == 0)) return CRT_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (fn == 100) {
         // every float bit pattern through the reciprocal the kernels use and through the division it stands for:

@@ -129,10 +129,9 @@ struct DevScene {
     uint32_t contexts;               // query contexts (stack column + parked state) per block, 0: the kernel without regrouping
     uint32_t keep_box, keep_leaf, keep_node, keep_exchange;   // a wave stays with its operation, without a vote, while it can fill this many lanes for it
     uint32_t exchange_first;         // an exchange (results out, new queries in) goes before any other operation once it can fill this many lanes
-    uint32_t run_min, run_patience;  // a wave that could fill fewer lanes than run_min waits (for run_patience votes at most) instead of starting an operation
-    uint32_t park_min;               // lanes that wait for another operation are parked once they are this many (or their lanes are needed)
     uint32_t burst_max;              // turns of one operation between two votes, at most
     uint32_t pair_below;             // a light sample's shadow query and the next segment's query start together while fewer than this many queries wait for traversal lanes
+    uint32_t fault_inject;           // tests: block 0 drops one ray query on the floor (the watchdog then ends the launch with an error)
     unsigned long long watchdog_ticks;   // 100 MHz ticks a wave may find nothing to do before it reports a protocol error
     // Candidate mask of the scene-node scan (see scan_candidates in kernels.hip).  drift_rel / drift_abs bound how
     // far a ray can move over one whole query through the ToLocal / FromLocal round trips of the nodes it enters:
@@ -171,6 +170,7 @@ struct DevPartition {
     // queue does not change any result.
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    uint32_t self_reset;         // the launch leaves the pixel queue's counter at zero for the next one (no memset between launches)
 };
 
 struct DevStats {

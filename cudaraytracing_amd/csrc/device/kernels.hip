@@ -1162,7 +1162,6 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             // queries within reach of its lanes is next.
             uint32_t mode = S_POST;
             uint32_t fruitless = 0;      // votes in a row after which no lane of the wave moved
-            uint32_t waited = 0;         // votes in a row at which the wave chose to wait for more queries
             // turns of one traversal operation, until too few lanes can be filled for it
             auto run = [&](auto op_tag, uint32_t keep) {
                 constexpr uint32_t kOp = decltype(op_tag)::value;
@@ -1253,11 +1252,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                         if (!idle_wait()) break;
                         continue;
                     }
-                    // few queries within reach, and not for long yet: let them gather (the waves that run meanwhile run fuller)
-                    if (best_c < S.run_min && waited < S.run_patience) { waited++; fruitless = 0; __builtin_amdgcn_s_sleep(2); continue; }
                     mode = best;
                 }
-                waited = 0;
                 idle_polls = 0;
                 if (kCount) tally.cycles[8] += __builtin_amdgcn_s_memtime() - t_vote;
                 if (mode == S_BOX) run(std::integral_constant<uint32_t, S_BOX>{}, S.keep_box);
@@ -1856,6 +1852,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
 
         // ---- the loop of a shading wave: take up to 64 slots, shade them, hand each one on
         uint32_t patience = 0;
+        bool fault_done = false;
         for (;;) {
             // Full turns when the traversal lanes have queries in reserve; while their queue runs low a partial turn
             // is better than letting them idle.
@@ -1881,7 +1878,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (kCount) { t_start = __builtin_amdgcn_s_memtime(); tally.turns[3]++; tally.lanes[3] += have; }
             const uint32_t result = which == 0 ? serve(std::true_type{}, have, slot) : serve(std::false_type{}, have, slot);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            queue_push<kRLog>(&ctl.tail[kQRay], ray_ring, result == R_RAY || result == R_TWO_RAYS, slot);
+            // fault injection (tests of the error path): one query of block 0 is never queued, so its slot never comes back
+            bool lost = false;
+            if (S.fault_inject && !fault_done && blockIdx.x == 0 && __ballot(result == R_RAY) != 0) { lost = result == R_RAY && lane_rank(__ballot(result == R_RAY)) == 0; fault_done = true; }
+            queue_push<kRLog>(&ctl.tail[kQRay], ray_ring, (result == R_RAY && !lost) || result == R_TWO_RAYS, slot);
             queue_push<kRLog>(&ctl.tail[kQRay], ray_ring, result == R_TWO_RAYS, slot | kSecond);
             queue_push<kQLog>(&ctl.tail[kQShade1], shade_ring[1], result == R_REFETCH, slot);
             const unsigned long long retired = __ballot(result == R_RETIRE);
@@ -1914,6 +1914,15 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         }
     }
     if (lds_ld(&ctl.abort) != 0 && tid == 0) atomicAdd(&stats->errors, 1ull);
+    // The pixel queue's counter resets itself when the launch is told to (the entry point that must not even enqueue a
+    // memset): queue[1] counts the blocks that are through, and the last one clears both words for the next launch.
+    if (P.self_reset) {
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            if (atomicAdd(&queue[1], 1u) == gridDim.x - 1u) { queue[0] = 0; queue[1] = 0; __threadfence(); }
+        }
+    }
     if (kCount && !kPrimary) {
 #pragma unroll
         for (int k = 0; k < 12; k++) {

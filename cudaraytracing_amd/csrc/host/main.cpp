@@ -34,6 +34,11 @@ static bool render_one(crt::Renderer& r, const crt::RenderSettings& st, const st
     const auto t1 = std::chrono::steady_clock::now();
     r.BeginRendering(true);
     const auto t2 = std::chrono::steady_clock::now();
+    if (!r.LastRenderOk()) {      // no image file for a frame that is not complete
+        std::lock_guard<std::mutex> guard(g_print);
+        printf("ERROR: %s was not rendered: %s\n", scene.c_str(), r.LastError().c_str());
+        return false;
+    }
     const bool saved = r.GetImage().SaveImage(out.c_str());
     const auto t3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -95,6 +100,12 @@ int main(int argc, char** argv) {
             return 1;
         }
         std::sort(files.begin(), files.end());
+        // a worker on a device that does not exist would take frames from the queue only to fail them
+        int have = 0;
+        if (crt_device_count(&have) != CRT_OK || st.device < 0 || st.device + devices > have) {
+            printf("ERROR: --device %d --devices %d asks for GPUs %d..%d, the machine has %d\n", st.device, devices, st.device, st.device + devices - 1, have);
+            return 2;
+        }
         mkdir(out_dir.c_str(), 0777);      // (an existing directory is fine)
         // Frames are independent: a queue of frames, one worker per (device, slot); each worker keeps one renderer
         // (one device context) and renders whole frames from scratch.

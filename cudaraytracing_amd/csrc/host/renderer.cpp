@@ -71,13 +71,21 @@ void Renderer::BeginRendering(const bool wait) {
 void Renderer::DoRendering() {
     lastKernelMs = 0; lastRays = 0;
     image.passes = 0;
-    if (!ctx || !scene || crt_clear(ctx) != CRT_OK) { rendering = false; return; }
+    lastOk = false;
+    if (!ctx || !scene || crt_clear(ctx) != CRT_OK) {
+        lastError = ctx ? crt_last_error(ctx) : "no scene loaded";
+        printf("ERROR: %s\n", lastError.c_str());
+        rendering = false;
+        return;
+    }
+    bool ok = true;
     for (int pass = 0; pass < settings.passes; pass++) {
         if (crt_render_pass(ctx, pass, settings.samples, nullptr, 0) != CRT_OK ||
             crt_convert(ctx, 1.0f / static_cast<float>(pass + 1), srgb, nullptr, nullptr, 0) != CRT_OK ||
             crt_read_image(ctx, &image.pixels[0].r) != CRT_OK) {
             lastError = crt_last_error(ctx);
             printf("ERROR: %s\n", lastError.c_str());
+            ok = false;
             break;
         }
         float ms = 0;
@@ -86,6 +94,13 @@ void Renderer::DoRendering() {
     }
     crt_stats st;
     if (crt_get_stats(ctx, &st) == CRT_OK) lastRays = st.closest_rays + st.shadow_rays;
+    else if (ok) {
+        // (a kernel that gave up shows here at the latest: the counters carry its error count)
+        lastError = crt_last_error(ctx);
+        printf("ERROR: %s\n", lastError.c_str());
+        ok = false;
+    }
+    lastOk = ok;
     image.passes++;
     rendering = false;
 }

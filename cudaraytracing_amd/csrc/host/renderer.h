@@ -59,6 +59,8 @@ public:
     double LastRenderKernelMs() const { return lastKernelMs; }
     uint64_t LastRenderRays() const { return lastRays; }
     const std::string& LastError() const { return lastError; }
+    // false when the last BeginRendering did not complete every pass (the image is then incomplete)
+    bool LastRenderOk() const { return lastOk.load(); }
 
 private:
     void DoRendering();
@@ -74,6 +76,7 @@ private:
     double lastKernelMs = 0;
     uint64_t lastRays = 0;
     std::string lastError;
+    std::atomic<bool> lastOk{false};
 };
 
 }  // namespace crt

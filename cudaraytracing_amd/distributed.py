@@ -28,23 +28,38 @@ def _row_indices(parts, height, strip_rows, device):
     return _INDEX_CACHE[key]
 
 
+_BUFFER_CACHE = {}
+
+
+def _gather_buffers(local, parts, max_rows, is_dst):
+    """Staging buffers of one image shape, allocated once: the packed rows of this rank and, on the destination rank, one
+    receive buffer per rank and the assembled image."""
+    key = (tuple(local.shape), local.dtype, str(local.device), parts, is_dst)
+    if key not in _BUFFER_CACHE:
+        packed = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        bufs = [torch.empty_like(packed) for _ in range(parts)] if is_dst else None
+        out = torch.empty_like(local) if is_dst else None
+        _BUFFER_CACHE[key] = (packed, bufs, out)
+    return _BUFFER_CACHE[key]
+
+
 def gather_rows(local, part, parts, strip_rows=16, dst=0, group=None):
     """Gather the owned rows of every rank's (H, W, C) tensor to rank `dst`.
 
     `local` holds valid data in the rows this rank owns.  Returns the assembled
-    (H, W, C) tensor on `dst` and None elsewhere.  With parts == 1 returns `local`."""
+    (H, W, C) tensor on `dst` and None elsewhere.  With parts == 1 returns `local`.
+    The staging buffers and the assembled image are allocated once per image shape and
+    reused: the returned tensor is overwritten by the next call with the same shape."""
     if parts == 1:
         return local
     H = local.shape[0]
     idx = _row_indices(parts, H, strip_rows, local.device)
     max_rows = max(int(i.numel()) for i in idx)
-    packed = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    packed, bufs, out = _gather_buffers(local, parts, max_rows, part == dst)
     mine = idx[part]
-    packed[: mine.numel()] = local.index_select(0, mine)
+    torch.index_select(local, 0, mine, out=packed[: mine.numel()])
     if part == dst:
-        bufs = [torch.empty_like(packed) for _ in range(parts)]
         dist.gather(packed, gather_list=bufs, dst=dst, group=group)
-        out = torch.empty_like(local)
         for p in range(parts):
             out.index_copy_(0, idx[p], bufs[p][: idx[p].numel()])
         return out

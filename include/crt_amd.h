@@ -186,6 +186,11 @@ void crt_free(void* p);
 
 typedef struct crt_ctx crt_ctx;
 
+/* Number of GPUs crt_create accepts (device = 0 .. count - 1).  The reference renders on whatever device the
+ * CUDA runtime selects (renderer/renderer.cu:21-24, no cudaSetDevice); the sequence front end uses this to
+ * refuse a --devices count the machine does not have. */
+int crt_device_count(int* count);
+
 int crt_create(int device, crt_ctx** out);
 void crt_destroy(crt_ctx* ctx);
 const char* crt_last_error(const crt_ctx* ctx);
@@ -220,13 +225,19 @@ int crt_render_pass(crt_ctx* ctx, int pass_id, int samples, void* stream, int as
  * and ray counters as crt_render_pass, bit for bit; the kernel's workspace
  * (pixel-queue counter, sequence-jump matrix, per-lane path state) is a fixed
  * 32 MiB array inside the library's code object, one copy per GPU, instead of
- * buffers from hipMalloc, and the call makes no allocation on the device (a
- * pass_id > 0 seen for the first time computes its jump matrix on the host).
- * The grid shrinks to the lanes whose state fits; a scene whose BVH is so deep
- * that one block's state does not fit fails with CRT_E_LIMIT.  Tiles are
- * handed out in storage order and no kernel time is recorded.  Every call on
- * one GPU, from any context, shares that GPU's array: calls that overlap on
- * one GPU race and must be ordered by the caller. */
+ * buffers from hipMalloc; the jump matrices of passes 1 .. 63 are written into
+ * it when the library first meets the GPU (crt_create), so the call itself
+ * allocates nothing and copies nothing: it enqueues the kernel and nothing
+ * else.  With async != 0 it makes no call that stream capture forbids
+ * and can be recorded into a HIP graph (async == 0 waits for the stream, which
+ * capture does not allow, and then reports a kernel that gave up like
+ * crt_render_pass does).  pass_id >= 64 fails with CRT_E_LIMIT.  The grid
+ * shrinks to the lanes whose state fits; a scene whose BVH is so deep that one
+ * block's state does not fit fails with CRT_E_LIMIT.  Tiles are handed out in
+ * storage order and no kernel time is recorded.  Every call on one GPU, from
+ * any context, shares that GPU's array: calls that overlap on one GPU race and
+ * must be ordered by the caller (replays of a recorded graph included: wait for
+ * one launch of the graph before the next). */
 int crt_render_pass_noalloc(crt_ctx* ctx, int pass_id, int samples, void* stream, int async);
 
 /* ConvertColors<<<...>>>(results, out, N, sRGB, pass_mul) (math/color.cu:19-23,

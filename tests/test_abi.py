@@ -34,7 +34,7 @@ def test_struct_sizes_match_the_c_side():
     assert ctypes.sizeof(capi.Node) == 136
     assert ctypes.sizeof(capi.Material) == 36
     assert ctypes.sizeof(capi.Light) == 32
-    assert ctypes.sizeof(capi.Stats) == 96 + 256 + 16 + 8
+    assert ctypes.sizeof(capi.Stats) == 96 + 3 * 96 + 64 + 16 + 8
 
 
 def test_environment_overrides_are_range_checked():

@@ -72,3 +72,46 @@ def test_a_missing_scene_is_an_error_not_an_empty_image(tmp_path):
     r = subprocess.run([CRT_RENDER, str(tmp_path / "nothing.xml"), "-o", str(tmp_path / "x.png")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "ERROR" in r.stdout
     assert not (tmp_path / "x.png").exists()
+
+
+def test_a_kernel_that_gives_up_fails_the_frame(tmp_path, monkeypatch):
+    """A trace kernel that loses a query (fault injection) is ended by its watchdog; the library must say so at the
+    render call, and the command-line front end must not write an image for the frame."""
+    import cudaraytracing_amd as crt
+    monkeypatch.setenv("CRT_FAULT_INJECT", "1")
+    monkeypatch.setenv("CRT_WATCHDOG_SECONDS", "1")
+    s = crt.Scene.load_file(scene_path("proj13_box"))
+    s.set_resolution(128, 72)
+    ctx = crt.Context(0)
+    try:
+        ctx.upload(s)
+        with pytest.raises(crt.CrtError, match="protocol error"):
+            ctx.render_pass(0, 2)
+        with pytest.raises(crt.CrtError, match="protocol error"):
+            ctx.read_image()
+        # the next frame of the same context starts clean
+        monkeypatch.delenv("CRT_FAULT_INJECT")
+        ctx.upload(s)
+        ctx.clear()
+        ctx.render_pass(0, 2)
+        ctx.convert(1.0, s.srgb)
+        assert np.array_equal(ctx.read_image(), oracle_image("proj13_box", 128, 72, 2, 1))
+    finally:
+        ctx.close()
+    monkeypatch.setenv("CRT_FAULT_INJECT", "1")
+    out = tmp_path / "broken.png"
+    r = subprocess.run([CRT_RENDER, scene_path("proj13_box"), "-o", str(out), "--spp", "2", "--passes", "1", "--width", "128", "--height", "72"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "protocol error" in r.stdout, r.stdout + r.stderr
+    assert not out.exists()
+
+
+def test_sequence_refuses_devices_the_machine_does_not_have(tmp_path):
+    src = tmp_path / "frames"
+    src.mkdir()
+    shutil.copy(scene_path("proj13_box"), src / "a.crtscene")
+    n = ctypes.c_int()
+    capi.check_host(capi.lib().crt_device_count(ctypes.byref(n)))
+    r = subprocess.run([CRT_RENDER, "--sequence", str(src), "--out-dir", str(tmp_path / "out"), "--devices", str(n.value + 1), "--spp", "1"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "the machine has" in r.stdout, r.stdout + r.stderr
