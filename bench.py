@@ -77,17 +77,25 @@ def profiled_counters(config):
         index = json.load(open(os.path.join(ROOT, "profiles", "latest.json")))
         path = os.path.join(ROOT, "profiles", index[config])
         sums, launches, digest = {}, {}, None
+        kernel_seconds = None
         for line in open(path):
             if line.startswith("# kernel_source_sha1:"):
                 digest = line.split(":", 1)[1].strip()
             f = line.split()
             if "trace_kernel<false," in line and len(f) >= 3 and f[-1].startswith("["):
                 sums[f[-3]] = float(f[-2]); launches[f[-3]] = float(f[-1].strip("[]"))
-    except (OSError, KeyError, ValueError):
+            elif line.startswith('"') and "trace_kernel<false," in line and kernel_seconds is None:
+                import csv
+                row = next(csv.reader([line]))          # --stats: name, calls, total ns, average ns, ...
+                kernel_seconds = float(row[3]) * 1e-9
+    except (OSError, KeyError, ValueError, IndexError, StopIteration):
         return None, "no committed counter summary for this workload"
     if digest != kernel_source_digest():
         return None, "the committed counter summary was measured on other kernel sources (re-run tools/profile_bench.sh)"
-    return {k: v / launches[k] for k, v in sums.items() if launches[k]}, os.path.relpath(path, ROOT)
+    per_launch = {k: v / launches[k] for k, v in sums.items() if launches[k]}
+    if kernel_seconds:
+        per_launch["kernel_seconds"] = kernel_seconds     # average duration of the kernel in the --stats pass of the same command
+    return per_launch, os.path.relpath(path, ROOT)
 
 
 def cpu_model():
@@ -124,7 +132,7 @@ def progress(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
@@ -137,41 +145,27 @@ def main():
     ap.add_argument("--copies", type=int, default=1582, help="config 5: teapot copies")
     ap.add_argument("--cpu-spp", type=int, default=24, help="samples per pixel of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-counters", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="default run only: leave out the short run of the ten-million-triangle configuration")
+    return ap.parse_args()
+
+
+def fill_defaults(args):
+    """Workload defaults of the chosen configuration; returns True when the workload is the BASELINE.json configuration itself."""
     synthetic = args.config == 5
     if synthetic:
         args.scene = args.scene or "proj5_box"
         args.width, args.height, args.spp = args.width or 3840, args.height or 2160, args.spp or 256
         args.steps = args.steps or 2
-    else:
-        args.scene = args.scene or "final_frame0042"
-        args.width, args.height, args.spp = args.width or 1920, args.height or 1080, args.spp or 64
-        args.steps = args.steps or 5
-    headline = (not synthetic and (args.scene, args.width, args.height, args.spp) == ("final_frame0042", 1920, 1080, 64)) or \
-               (synthetic and (args.copies, args.width, args.height, args.spp) == (1582, 3840, 2160, 256))
+        return (args.copies, args.width, args.height, args.spp) == (1582, 3840, 2160, 256)
+    args.scene = args.scene or "final_frame0042"
+    args.width, args.height, args.spp = args.width or 1920, args.height or 1080, args.spp or 64
+    args.steps = args.steps or 5
+    return (args.scene, args.width, args.height, args.spp) == ("final_frame0042", 1920, 1080, 64)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
-        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    # Rehearsal of the multi-rank path on a box with one GPU (CRT_BENCH_REHEARSAL=1): every rank renders on device 0
-    # and the collectives run over gloo on host copies.  Its timings mean nothing; it exists to exercise the code.
-    rehearsal = os.environ.get("CRT_BENCH_REHEARSAL", "0") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    coll_device = torch.device("cpu") if rehearsal else device
 
+def run_workload(args, headline, rank, world, local_rank, device, coll_device, rehearsal):
+    """Times args.steps frames of one workload and returns rank 0's result object (None on the other ranks)."""
+    synthetic = args.config == 5
     scene_file = os.path.join(ROOT, "tests", "golden", "scenes", args.scene + ".crtscene")
     scene = crt.Scene.load_file(scene_file)
     if synthetic:
@@ -216,8 +210,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    progress(f"upload {upload_ms:.0f} ms; {args.warmup} warm-up frame(s)")
-    for _ in range(args.warmup):
+    # The first frame after an upload hands tiles out in storage order; from the second one on the order is costliest
+    # first, by the cost the frame before measured.  The first frame is therefore always run, timed on its own and
+    # reported (first_frame_ms); it counts as one of the warm-up frames.
+    progress(f"upload {upload_ms:.0f} ms; first frame (tiles in storage order), then {max(args.warmup - 1, 0)} more warm-up frame(s)")
+    fence()
+    t0 = time.perf_counter()
+    frame()
+    fence()
+    first_frame_ms = (time.perf_counter() - t0) * 1e3
+    first_kernel = ctx.kernel_times()
+    for _ in range(max(args.warmup - 1, 0)):
         frame()
     fence()
     ctx.kernel_times()                      # drop warm-up launches
@@ -234,64 +237,21 @@ def main():
 
     st = ctx.stats()                        # counters of the last frame (cleared at each frame start); raises on a kernel protocol error
     rays = torch.tensor([st["closest_rays"] + st["shadow_rays"], st["closest_rays"], st["shadow_rays"]], dtype=torch.float64, device=coll_device)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+    t = torch.tensor([elapsed, first_frame_ms], dtype=torch.float64, device=coll_device)
     per_rank = torch.zeros(world * 2, dtype=torch.float64, device=coll_device)
     per_rank[2 * rank], per_rank[2 * rank + 1] = k_ms, g_ms
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    elapsed, first_frame_ms = float(t[0].item()), float(t[1].item())
     rays_per_frame = float(rays[0].item())
     ms_per_step = elapsed / args.steps * 1e3
     per_rank = per_rank.cpu().tolist()
 
     roofline = None
     if rank == 0 and not args.no_roofline_counters:
-        # traversal counters of this rank's share of the frame, from the counting build of the kernel (untimed)
-        progress(f"{ms_per_step:.1f} ms per frame; counting traversal work (untimed)")
-        ctx.clear()
-        ctx.render_pass_counted(0, args.spp if not synthetic else min(args.spp, 8))
-        c = ctx.stats()
-        if synthetic and args.spp > 8:      # the counted build is slow: count 8 spp and scale (every sample does the same kind of work)
-            c = {k: v * args.spp / 8.0 for k, v in c.items()}
-        ctx.kernel_times()
-        own_pixels = sum(1 for y in range(H) if (y // STRIP_ROWS) % world == rank) * W
-        nbytes, flops = algorithmic_work(c, own_pixels)
-        prof, prof_note = profiled_counters("config5" if synthetic else "config3") if (headline and world == 1) else (None, "no committed counter summary for this workload")
-        gbs = nbytes / (k_ms * 1e-3) * 1e-9
-        tfs = flops / (k_ms * 1e-3) * 1e-12
-        traffic = issue = lanes = clock_ghz = None
-        if prof:
-            if "FETCH_SIZE" in prof and "WRITE_SIZE" in prof:
-                traffic = (prof["FETCH_SIZE"] + prof["WRITE_SIZE"]) * 1024.0          # KiB counters
-            if "GRBM_GUI_ACTIVE" in prof and "SQ_INSTS_VALU" in prof:
-                cycles = prof["GRBM_GUI_ACTIVE"] / 8.0                                # the counter sums the 8 XCDs
-                issue = prof["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles)               # 4 issue cycles per wave64 instruction, 1024 SIMDs
-            if "SQ_THREAD_CYCLES_VALU" in prof and prof.get("SQ_ACTIVE_INST_VALU"):
-                lanes = prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"]
-        hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-               "traffic": traffic,
-               "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch (separate rocprofv3 --pmc passes; gfx950 tallies 128-byte read requests as 64 bytes, "
-                               "so the read half is a lower bound; Infinity Cache hits are included), from " + prof_note if traffic else prof_note,
-               "algorithmic_bytes_per_launch": nbytes}
-        valu = {"bound": "valu", "achieved": tfs, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP32_VECTOR_PEAK_TFLOPS,
-                "peak_note": "157.3 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz; against the lane-operation rate without "
-                             "the FMA factor (256 CUs x 128 lanes x 2.4 GHz = 78.6 Tlane-op/s) the fraction doubles; the kernel is built without contraction",
-                "frac_of_lane_op_rate": tfs / (FP32_VECTOR_PEAK_TFLOPS / 2.0),
-                "algorithmic_flops_per_launch": flops,
-                "vector_issue_slots_used": issue, "active_lanes_per_vector_instruction": lanes,
-                "counters_from": prof_note if prof else None,
-                "counters_note": None if prof else prof_note}
-        # The binding limit goes on top: vector instruction issue for the cache-resident scenes, HBM for the scene no cache holds.
-        top, nested = (hbm, valu) if synthetic else (valu, hbm)
-        roofline = dict(top)
-        roofline.update({"kernel": "trace_kernel", "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(kernel_ms)),
-                         "traffic": traffic, "other": nested,
-                         "note": "no MFMA on this path (not a dense contraction). algorithmic work = traversal counters of the counting build "
-                                 "of the kernel (full scene-node scan and every BVH expansion, as the reference walks them) priced by the rule in "
-                                 "bench.py::algorithmic_work, divided by the measured duration of the plain kernel; the plain kernel passes over "
-                                 "scene nodes and BVH children that are certain to be missed, so it fetches less than that (see traffic)"})
+        roofline = price_roofline(args, ctx, scene, synthetic, headline, world, rank, k_ms, len(kernel_ms), ms_per_step)
 
     if rehearsal and rank == 0 and world > 1:
         # the gathered frame must equal a frame rendered by one context alone
@@ -324,12 +284,16 @@ def main():
         else:
             cpu = cpu_baseline(scene_file, scene_label, W, H, args.cpu_spp, args.spp, threads)
 
+    out = None
     if rank == 0:
         cfg_name = "BASELINE.json configs[4]" if synthetic else "BASELINE.json configs[3]"
         out = {
             "metric": f"Mrays/s ({'synthetic 10M triangles, 4K, 256 spp' if synthetic else 'scenes/final, 1080p, 64 spp'})",
             "value": rays_per_frame / (ms_per_step * 1e-3) * 1e-6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step,
+            "first_frame_ms": first_frame_ms, "first_frame_kernel_ms": float(first_kernel[0]) if len(first_kernel) else None,
+            "first_frame_note": "the first frame after the scene upload hands tiles out in storage order (what a single crt_render of a scene pays); "
+                                "the timed frames use the tile costs the frame before them measured",
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic scene generated from the reference's teapot mesh, fixed seeds" if synthetic else "reference scene file (baked), fixed seeds",
             "config": {"workload": f"{scene_label} at {W}x{H}, {args.spp} spp in 1 pass, path-traced GI" + (f" ({cfg_name})" if headline else " (not a BASELINE.json configuration)"),
@@ -338,12 +302,137 @@ def main():
             "rays_per_frame": rays_per_frame, "closest_rays": float(rays[1].item()), "shadow_rays": float(rays[2].item()),
             "frame_includes": "accumulator clear, trace kernel, ConvertColors, row gather, D2H of the 8-bit image",
             "per_rank": [{"rank": r, "kernel_ms": per_rank[2 * r], "gather_ms": per_rank[2 * r + 1]} for r in range(world)],
-            "scheduling": "tiles are handed out costliest first using the per-tile cost the previous frame measured (warm-up frame for the first timed one); results do not depend on the order",
+            "scheduling": "tiles are handed out costliest first using the per-tile cost the previous frame measured (first_frame_ms: the frame without that); results do not depend on the order",
             "scene_upload_ms": upload_ms,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
     ctx.close()
+    return out
+
+
+def price_roofline(args, ctx, scene, synthetic, headline, world, rank, k_ms, launches_timed, ms_per_step):
+    """The roofline object: algorithmic work of one launch (counting build of the kernel, untimed) over the measured
+    duration of the plain kernel, and what the committed counter passes over this same command measured."""
+    H, W = args.height, args.width
+    count_spp = args.spp if not synthetic else min(args.spp, 8)      # the counting build is slow: count 8 spp of the big scene and scale
+    scale = args.spp / float(count_spp)
+    own_pixels = sum(1 for y in range(H) if (y // STRIP_ROWS) % world == rank) * W
+
+    def counted(label):
+        progress(f"{ms_per_step:.1f} ms per frame; counting traversal work, {label} (untimed)")
+        ctx.clear()
+        ctx.render_pass_counted(0, count_spp)
+        c = {k: v * scale for k, v in ctx.stats().items()}
+        ctx.kernel_times()
+        return c
+
+    # 1. the walk as the reference takes it: every scene node's box, every BVH child a box test let through or not
+    c_ref = counted("the reference's walk")
+    bytes_ref, flops_ref = algorithmic_work(c_ref, own_pixels)
+    # 2. the walk the plain kernel takes: scene nodes by the candidate mask, no missed interior BVH children
+    os.environ["CRT_COUNTED_BY_MASK"] = "1"
+    try:
+        ctx.upload(scene)
+        ctx.set_partition(rank, world, STRIP_ROWS)
+        c_own = counted("the plain kernel's own walk")
+    finally:
+        del os.environ["CRT_COUNTED_BY_MASK"]
+    bytes_own, flops_own = algorithmic_work(c_own, own_pixels)
+
+    prof, prof_note = profiled_counters("config5" if synthetic else "config3") if (headline and world == 1) else (None, "no committed counter summary for this workload")
+    seconds = k_ms * 1e-3
+    traffic = issue = lanes = measured = None
+    if prof:
+        if "FETCH_SIZE" in prof and "WRITE_SIZE" in prof:
+            fetch, write = prof["FETCH_SIZE"] * 1024.0, prof["WRITE_SIZE"] * 1024.0          # KiB counters
+            traffic = fetch + write
+            kernel_s = prof.get("kernel_seconds", seconds)
+            measured = {"fetch_bytes": fetch, "write_bytes": write,
+                        "gbs_low": (fetch + write) / kernel_s * 1e-9, "gbs_high": (2.0 * fetch + write) / kernel_s * 1e-9,
+                        "frac_low": (fetch + write) / kernel_s * 1e-9 / HBM_PEAK_GBS, "frac_high": (2.0 * fetch + write) / kernel_s * 1e-9 / HBM_PEAK_GBS,
+                        "kernel_seconds": kernel_s,
+                        "note": "fabric-side bytes of the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate passes) over the kernel "
+                                "duration of those passes; gfx950 tallies a 128-byte read request as 64 bytes, so the read half lies between "
+                                "FETCH_SIZE and twice that (gbs_low / gbs_high); Infinity Cache hits are included"}
+        if "GRBM_GUI_ACTIVE" in prof and "SQ_INSTS_VALU" in prof:
+            cycles = prof["GRBM_GUI_ACTIVE"] / 8.0                                # the counter sums the 8 XCDs
+            issue = prof["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles)               # 4 issue cycles per wave64 instruction, 1024 SIMDs
+        if "SQ_THREAD_CYCLES_VALU" in prof and prof.get("SQ_ACTIVE_INST_VALU"):
+            lanes = prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"]
+    gbs_ref, gbs_own = bytes_ref / seconds * 1e-9, bytes_own / seconds * 1e-9
+    tfs_ref, tfs_own = flops_ref / seconds * 1e-12, flops_own / seconds * 1e-12
+    hbm = {"bound": "hbm", "achieved": gbs_own, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_own / HBM_PEAK_GBS,
+           "achieved_note": "algorithmic bytes of the walk the plain kernel takes (scene nodes by the candidate mask, no missed interior BVH children) "
+                            "over the kernel's measured duration; caches serve part of them, see `measured` for what crossed the fabric",
+           "algorithmic_bytes_per_launch": bytes_own,
+           "reference_walk": {"achieved": gbs_ref, "frac": gbs_ref / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_ref,
+                              "note": "the same rule priced on the walk the reference takes (every scene node's box, every pushed BVH child): work the plain kernel "
+                                      "proves unnecessary and skips, so not a bandwidth the kernel achieved"},
+           "traffic": traffic, "measured": measured,
+           "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch, from " + prof_note if traffic else prof_note}
+    valu = {"bound": "valu", "achieved": tfs_ref, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs_ref / FP32_VECTOR_PEAK_TFLOPS,
+            "achieved_note": "algorithmic flops of the reference's walk (the pricing rule counts every scene-node box test); on the plain kernel's own walk: `own_walk`",
+            "own_walk": {"achieved": tfs_own, "frac": tfs_own / FP32_VECTOR_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops_own},
+            "peak_note": "157.3 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz; against the lane-operation rate without "
+                         "the FMA factor (256 CUs x 128 lanes x 2.4 GHz = 78.6 Tlane-op/s) the fraction doubles; the kernel is built without contraction",
+            "frac_of_lane_op_rate": tfs_ref / (FP32_VECTOR_PEAK_TFLOPS / 2.0),
+            "algorithmic_flops_per_launch": flops_ref,
+            "vector_issue_slots_used": issue, "active_lanes_per_vector_instruction": lanes,
+            "counters_from": prof_note if prof else None,
+            "counters_note": None if prof else prof_note}
+    # The binding limit goes on top: vector instruction issue for the cache-resident scenes, memory for the scene no cache holds.
+    top, nested = (hbm, valu) if synthetic else (valu, hbm)
+    roofline = dict(top)
+    roofline.update({"kernel": "trace_kernel", "kernel_ms_avg": k_ms, "kernel_launches_timed": int(launches_timed),
+                     "traffic": traffic, "other": nested,
+                     "note": "no MFMA on this path (not a dense contraction). algorithmic work = traversal counters of the counting build of the kernel "
+                             "priced by the rule in bench.py::algorithmic_work, divided by the measured duration of the plain kernel"})
+    return roofline
+
+
+def main():
+    args = parse_args()
+    headline = fill_defaults(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    # Rehearsal of the multi-rank path on a box with one GPU (CRT_BENCH_REHEARSAL=1): every rank renders on device 0
+    # and the collectives run over gloo on host copies.  Its timings mean nothing; it exists to exercise the code.
+    rehearsal = os.environ.get("CRT_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    coll_device = torch.device("cpu") if rehearsal else device
+
+    out = run_workload(args, headline, rank, world, local_rank, device, coll_device, rehearsal)
+
+    # The default single-GPU run also witnesses the other BASELINE configuration that fits one GPU, in short form: the
+    # ten-million-triangle scene at 4K and 256 spp, one frame after the first one (scene generation and upload take
+    # ~15 s, a frame ~3 s).
+    if out is not None and world == 1 and args.config == 3 and headline and not args.no_secondary:
+        progress("secondary workload: BASELINE.json configs[4] (one timed frame)")
+        sec_args = argparse.Namespace(**vars(args))
+        sec_args.config, sec_args.scene, sec_args.width, sec_args.height, sec_args.spp = 5, None, None, None, None
+        sec_args.steps, sec_args.warmup, sec_args.cpu_spp = 1, 1, 0
+        sec_headline = fill_defaults(sec_args)
+        sec = run_workload(sec_args, sec_headline, rank, world, local_rank, device, coll_device, rehearsal)
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "first_frame_ms", "first_frame_kernel_ms", "dtype", "data", "config",
+                "rays_per_frame", "scene_upload_ms", "roofline")
+        out["secondary"] = {k: sec[k] for k in keep}
+
+    if out is not None:
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

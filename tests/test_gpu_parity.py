@@ -52,6 +52,16 @@ def test_pinned_math_is_bit_identical_on_device(gpu_ctx):
         assert np.array_equal(g.view(np.uint32)[~nan_both], c.view(np.uint32)[~nan_both]), fn
 
 
+def test_pinned_math_on_device_is_correctly_rounded(gpu_ctx):
+    """The device functions against an evaluation that shares nothing with them or with the oracle's copy of the
+    algorithm: numpy's 80-bit long double, rounded to float, a million operands per function."""
+    from test_detmath import reference_cases
+    for fn, a, b, want in reference_cases(1_000_000, seed=77):
+        got = gpu_ctx.math_selftest(fn, a, b)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (fn, int((~same).sum()))
+
+
 def test_seeded_sequence_matches(gpu_ctx):
     k = np.load(os.path.join(GOLDEN, "xorwow_kat.npz"))
     assert np.array_equal(gpu_ctx.rng_selftest(k["seeds"], k["subsequences"], 8), k["words"])
