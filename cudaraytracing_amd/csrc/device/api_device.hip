@@ -542,10 +542,13 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // latency, and there the kernels for deep trees (more queries in flight, 23 stack entries in LDS) are faster.
     ctx->regroup = crt::knob_value(getenv("CRT_REGROUP"), stack_total <= fit ? 1 : 0, 0, 1) != 0;
     if (ctx->regroup) {
-        // Regrouping kernels: a block has S.contexts query contexts, each with a stack column and 112 bytes of parked
+        // Regrouping kernels: 13 of the 16 waves traverse, and the last S.swing_waves of those take shading turns when the
+        // shading queues run long, so one split serves scenes with much and with little to walk through.
+        S.trav_waves = crt::knob_value(getenv("CRT_TRAV_WAVES"), 13, 1, CRT_BLOCK / 64 - 1);
+        // a block has S.contexts query contexts, each with a stack column and 112 bytes of parked
         // state in LDS; the LDS left beside the rings decides how many stack entries a column holds (the top of the
         // stack; older entries move to device memory).
-        S.contexts = crt::knob_value(getenv("CRT_CONTEXTS"), S.trav_waves * 64, 64, kMaxContexts) & ~63u;
+        S.contexts = crt::knob_value(getenv("CRT_CONTEXTS"), 768, 64, kMaxContexts) & ~63u;
         ctx->deep = false;
         size_t fixed = 0;
         for (int variant = 0; variant < 3; variant++) {
@@ -566,11 +569,15 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         ctx->deep = ctx->stack_overflow > 0 || S.stack_entries * lane_bytes > kLdsLimit;
     }
     S.stack_overflow = ctx->stack_overflow;
-    S.keep_box = crt::knob_value(getenv("CRT_KEEP_BOX"), 40, 1, 65);
-    S.keep_leaf = crt::knob_value(getenv("CRT_KEEP_LEAF"), 40, 1, 65);
-    S.keep_node = crt::knob_value(getenv("CRT_KEEP_NODE"), 40, 1, 65);
+    S.keep_box = crt::knob_value(getenv("CRT_KEEP_BOX"), 8, 1, 65);
+    S.keep_leaf = crt::knob_value(getenv("CRT_KEEP_LEAF"), 8, 1, 65);
+    S.keep_node = crt::knob_value(getenv("CRT_KEEP_NODE"), 8, 1, 65);
     S.keep_exchange = crt::knob_value(getenv("CRT_KEEP_EXCHANGE"), 40, 1, 65);
     S.exchange_first = crt::knob_value(getenv("CRT_EXCHANGE_FIRST"), 32, 1, 65);
+    S.first_step_idle = crt::knob_value(getenv("CRT_FIRST_STEP_IDLE"), 6, 0, 65);
+    S.direct_start = crt::knob_value(getenv("CRT_DIRECT_START"), 1, 0, 1);
+    S.swing_waves = crt::knob_value(getenv("CRT_SWING_WAVES"), 6, 0, 16);
+    S.swing_fill = crt::knob_value(getenv("CRT_SWING_FILL"), 128, 1, 1u << 20);
     S.burst_max = crt::knob_value(getenv("CRT_BURST_MAX"), 16, 1, 1u << 20);
     {
         // Drift bound of the scan's candidate mask.  One round trip through node j maps p to fl(tm * fl(itm * p)): its

@@ -129,6 +129,9 @@ struct DevScene {
     uint32_t contexts;               // query contexts (stack column + parked state) per block, 0: the kernel without regrouping
     uint32_t keep_box, keep_leaf, keep_node, keep_exchange;   // a wave stays with its operation, without a vote, while it can fill this many lanes for it
     uint32_t exchange_first;         // an exchange (results out, new queries in) goes before any other operation once it can fill this many lanes
+    uint32_t first_step_idle;        // ... or (queries started straight in contexts) while fewer than this many of the contexts within the lane's reach are free
+    uint32_t direct_start;           // shading lanes put a new query straight into a free query context when one is within reach
+    uint32_t swing_waves, swing_fill;   // this many of the traversal waves take a shading turn when at least swing_fill slots wait for one
     uint32_t burst_max;              // turns of one operation between two votes, at most
     uint32_t pair_below;             // a light sample's shadow query and the next segment's query start together while fewer than this many queries wait for traversal lanes
     uint32_t fault_inject;           // tests: block 0 drops one ray query on the floor (the watchdog then ends the launch with an error)
