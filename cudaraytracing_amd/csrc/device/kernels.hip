@@ -7,37 +7,47 @@
 // renderer/trace.cu:22-25); a finished slot takes the next pixel of a global
 // queue with one wave-aggregated atomic (ballot + mbcnt prefix).
 //
-// Slots, not lanes, own pixels.  Everything a pixel carries from one ray query
-// to the next lives in the slot's 320-byte record in global memory, and two
-// kinds of wave pass slots to each other through rings in LDS (positions
-// reserved with one atomic per wave, entries compacted with ballot + mbcnt):
-//   * traversal waves run ray queries.  A lane takes a ready query of whatever
-//     pixel, walks it, writes the result into the slot and queues the slot for
-//     shading.  The work of a query is cut into three operations - BOX: slab-test
-//     the two children of a BVH node (one 64-byte record); LEAF: up to two
-//     triangles of a leaf; NODE: one step of the scene-node scan (leave the mesh
-//     just walked, test the next node's box, enter it: transform, sphere / plane
-//     test or BVH root) - and each turn the wave votes (ballot + popcount) and
-//     runs one operation for the lanes that wait for it; closest-hit and shadow
-//     queries share all three.  The traversal stack lives in LDS, laid out
-//     [entry][thread] so that any mix of stack depths is bank-conflict free.
-//   * shading waves run everything between two queries of a pixel (hit
+// Slots, not lanes, own pixels: everything a pixel carries from one ray query to
+// the next lives in the slot's 320-byte record in global memory.  And queries,
+// not lanes, own traversal state: a query in flight has a context in LDS (112
+// bytes of state and a column of the traversal stack).  The work of a query is
+// cut into three operations - BOX: slab-test the two children of a BVH node (one
+// 64-byte record); LEAF: up to two triangles of a leaf; NODE: one step of the
+// scene-node scan (leave the mesh just walked, test the next node's box, enter
+// it: transform, sphere / plane test or BVH root) - shared by closest-hit and
+// shadow queries.
+//   * A traversal wave runs ONE operation per turn with as many lanes as it can
+//     fill.  A lane loads what the operation reads from its query's context,
+//     takes the step and stores what changed; a lane whose query now waits for
+//     another operation parks the context in that operation's pool (a bit per
+//     context, one word per lane position, one LDS atomic) and takes a parked
+//     context that waits for the wave's operation.  Contexts stay with their lane
+//     position (and its partner in the other half of the wave), so context
+//     records and stack columns are spread over the LDS banks like the lanes.
+//     Nothing of a query stays in a lane's registers from turn to turn.
+//   * Shading waves run everything between two queries of a pixel (hit
 //     attributes, textures, light and BSDF sampling, Russian roulette, the camera
 //     ray of a new path, the next pixel of a finished slot) for up to 64 slots
-//     at a time, whichever lanes finished them, in turns that are all of one
-//     kind (closest-hit query ended / shadow query ended or pixel needed).
+//     at a time, in turns that are all of one kind (closest-hit query ended /
+//     shadow query ended or pixel needed).  A new query goes straight into a free
+//     context and into the pool of its first operation (the slot's RAY record
+//     and the ray ring are the fall-back when no context is within reach); a
+//     query that has ended is written into the slot's HIT record by a traversal
+//     wave's exchange turn, and the slot goes into one of the two shading queues
+//     (rings in LDS: positions reserved with one atomic per wave, entries
+//     compacted with ballot + mbcnt).
+//   * Because a traversal wave holds nothing between turns, the last few of them
+//     take shading turns whenever the shading queues run long: the split between
+//     the two kinds of work follows the frame.
 // When a block runs short of pixels, a pixel's shadow query and the closest-hit
 // query of its next path segment run side by side (they are independent; the
 // results are joined in the reference's order), which shortens the chain of
 // dependent queries that bounds the end of a frame.
-// When a block runs short of pixels, a pixel's shadow query and the closest-hit
-// query of its next path segment run side by side (they are independent; the
-// results are joined in the reference's order), which shortens the chain of
-// dependent queries that bounds the end of a frame.
-// So both kinds of wave work with their lanes full of the same kind of work,
-// traversal state is the only thing in a traversal lane's registers, and the
-// kernel spills nothing.  The order of operations of any one pixel is exactly
-// the reference's; only their interleaving across pixels is scheduled.
+// The order of operations of any one pixel is exactly the reference's; only their
+// interleaving across pixels is scheduled.  (Trees deeper than the LDS stack run
+// the kernel variants without contexts - kRegroup false - in which a traversal
+// lane keeps its query in registers from start to end and the wave votes on the
+// operation of each turn.)
 //
 // Arithmetic keeps the reference's operation order (see crt_vec.h); the file is
 // compiled with -ffp-contract=off and uses the pinned transcendentals of
