@@ -102,6 +102,7 @@ _PROTOS = {
     "crt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "crt_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "crt_destroy": (None, [_VP]),
+    "crt_set_tlas": (C.c_int, [_VP, C.c_int]),
     "crt_last_error": (C.c_char_p, [_VP]),
     "crt_upload_scene": (C.c_int, [_VP, C.POINTER(SceneDesc)]),
     "crt_set_partition": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32]),

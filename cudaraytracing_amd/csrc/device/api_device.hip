@@ -33,6 +33,8 @@ struct crt_ctx {
     bool order_valid = false;
     bool deep = false;                         // BVH deeper than the LDS stack: kDeep kernels
     bool regroup = false;                      // the kernels whose waves regroup queries by operation (kRegroup)
+    bool want_tlas = false;                    // crt_set_tlas: asked for by the caller, takes effect at the next upload
+    bool tlas = false;                         // the uploaded scene is walked through a BVH over its object nodes (kTlas)
     uint32_t stack_overflow = 0;               // stack entries per thread kept in the side buffer
     bool interleave = false;                   // tile order: expensive and cheap tiles alternate
     bool no_balance = false;                   // CRT_NO_BALANCE=1: always hand tiles out in storage order
@@ -270,6 +272,100 @@ void subtree_ends(const crt_scene_desc* d, std::vector<uint32_t>& after) {
     }
 }
 
+// A BVH over the object nodes of the scene (no counterpart in the reference, which scans its node list from end to
+// end for every ray: renderer/trace.cu:51, 166).  Each object's box is the box of its own geometry in world space -
+// the unit sphere, the unit plane or the mesh's bounds carried through the node's matrix - not the node's box of the
+// scene file, which also spans the node's children.  Binary tree by a sweep of the surface-area cost over the centres
+// sorted along each axis; interior records are appended to `pairs`, a child that is an object is a reference with
+// count kTlasEnter and the node's index.  root: the reference to start from (an empty leaf when the scene has no
+// object); depth: interior levels above the deepest object.
+void tlas_build(const crt_scene_desc* d, std::vector<BoxPair>& pairs, uint32_t& root, uint32_t& depth) {
+    struct Item { float lo[3], hi[3]; uint32_t node; };
+    std::vector<Item> items;
+    for (uint32_t i = 0; i < d->node_count; i++) {
+        const crt_node& n = d->nodes[i];
+        double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+        if (n.object_kind == CRT_OBJ_NONE) continue;
+        if (n.object_kind == CRT_OBJ_PLANE) lo[2] = hi[2] = 0;
+        if (n.object_kind == CRT_OBJ_MESH) {
+            const crt_mesh& M = d->meshes[n.mesh_id];
+            if (M.nf == 0) continue;
+            for (int k = 0; k < 3; k++) { lo[k] = M.box_min[k]; hi[k] = M.box_max[k]; }
+        }
+        double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+        bool finite = true;
+        for (int corner = 0; corner < 8; corner++) {
+            const double p[3] = {(corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]};
+            for (int row = 0; row < 3; row++) {
+                const double w = (double)n.tm[row] * p[0] + (double)n.tm[3 + row] * p[1] + (double)n.tm[6 + row] * p[2] + (double)n.tm[9 + row];
+                if (!(w == w) || fabs(w) > 1e30) finite = false;
+                wlo[row] = fmin(wlo[row], w); whi[row] = fmax(whi[row], w);
+            }
+        }
+        Item it;
+        it.node = i;
+        // The object is tested in its own space with a ray that went through the node's inverse matrix in single
+        // precision: the box is widened by far more than that rounding, so that no hit of the object lies outside it.
+        double reach = 0;
+        for (int k = 0; k < 3; k++) reach = fmax(reach, fmax(fabs(wlo[k]), fabs(whi[k])));
+        const double pad = 1e-4 * reach + 1e-6;
+        for (int k = 0; k < 3; k++) {
+            it.lo[k] = finite ? (float)(wlo[k] - pad) : -CRT_BIGFLOAT;
+            it.hi[k] = finite ? (float)(whi[k] + pad) : CRT_BIGFLOAT;
+        }
+        items.push_back(it);
+    }
+    depth = 0;
+    root = make_leaf_ref(0, 0);
+    if (items.empty()) return;
+    auto grow = [](float* lo, float* hi, const Item& it) { for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], it.lo[k]); hi[k] = fmaxf(hi[k], it.hi[k]); } };
+    auto half_area = [](const float* lo, const float* hi) -> double {
+        const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    };
+    std::vector<double> right_area;
+    // items [b, e) -> the reference of their subtree and its box
+    std::function<uint32_t(uint32_t, uint32_t, uint32_t, float*, float*)> build = [&](uint32_t b, uint32_t e, uint32_t level, float* lo, float* hi) -> uint32_t {
+        for (int k = 0; k < 3; k++) { lo[k] = CRT_BIGFLOAT; hi[k] = -CRT_BIGFLOAT; }
+        for (uint32_t i = b; i < e; i++) grow(lo, hi, items[i]);
+        if (e - b == 1) return make_leaf_ref(items[b].node, kTlasEnter);
+        if (level + 1 > depth) depth = level + 1;
+        int best_axis = 0;
+        uint32_t best_cut = (b + e) / 2;
+        double best_cost = 1e300;
+        for (int axis = 0; axis < 3 && level < 48; axis++) {      // (beyond 48 levels: halve, whatever the cost says)
+            std::sort(items.begin() + b, items.begin() + e, [axis](const Item& x, const Item& y) {
+                const float cx = x.lo[axis] + x.hi[axis], cy = y.lo[axis] + y.hi[axis];
+                return cx < cy || (cx == cy && x.node < y.node);
+            });
+            right_area.assign(e - b + 1, 0.0);
+            float rl[3] = {CRT_BIGFLOAT, CRT_BIGFLOAT, CRT_BIGFLOAT}, rh[3] = {-CRT_BIGFLOAT, -CRT_BIGFLOAT, -CRT_BIGFLOAT};
+            for (uint32_t i = e; i-- > b + 1;) { grow(rl, rh, items[i]); right_area[i - b] = half_area(rl, rh); }
+            float ll[3] = {CRT_BIGFLOAT, CRT_BIGFLOAT, CRT_BIGFLOAT}, lh[3] = {-CRT_BIGFLOAT, -CRT_BIGFLOAT, -CRT_BIGFLOAT};
+            for (uint32_t cut = b + 1; cut < e; cut++) {
+                grow(ll, lh, items[cut - 1]);
+                const double cost = half_area(ll, lh) * (cut - b) + right_area[cut - b] * (e - cut);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_cut = cut; }
+            }
+        }
+        std::sort(items.begin() + b, items.begin() + e, [best_axis](const Item& x, const Item& y) {
+            const float cx = x.lo[best_axis] + x.hi[best_axis], cy = y.lo[best_axis] + y.hi[best_axis];
+            return cx < cy || (cx == cy && x.node < y.node);
+        });
+        const size_t rec = pairs.size();
+        pairs.push_back(BoxPair{});
+        float la[3], ha[3], lb[3], hb[3];
+        const uint32_t ref_a = build(b, best_cut, level + 1, la, ha);
+        const uint32_t ref_b = build(best_cut, e, level + 1, lb, hb);
+        BoxPair& p = pairs[rec];
+        set_box(p.a, la, ha); set_box(p.b, lb, hb);
+        p.ref_a = ref_a; p.ref_b = ref_b; p.aux_a = p.aux_b = 0;
+        return (uint32_t)rec;
+    };
+    float lo[3], hi[3];
+    root = build(0, (uint32_t)items.size(), 0, lo, hi);
+}
+
 // queue items of the whole image cut into strips of strip_rows rows (padded to whole 8x8 tiles)
 uint64_t partition_items(const DevScene& S, uint32_t strip_rows) {
     const uint64_t strips = (S.height + strip_rows - 1) / strip_rows;
@@ -310,7 +406,8 @@ uint32_t trace_grid(const crt_ctx* ctx, int per_cu) {
 using TraceKernel = void (*)(DevScene, DevPartition, int, const uint32_t*, uint32_t*, DevStats*, int32_t*, int32_t*, float*, uint32_t*);
 
 template <bool kCount, bool kPrimary>
-TraceKernel trace_variant(bool deep, bool wide, bool regroup) {
+TraceKernel trace_variant(bool deep, bool wide, bool regroup, bool tlas) {
+    if (tlas) return trace_kernel<kCount, kPrimary, false, false, true, true>;
     if (regroup) return wide ? trace_kernel<kCount, kPrimary, false, true, true> : trace_kernel<kCount, kPrimary, false, false, true>;
     if (deep) return wide ? trace_kernel<kCount, kPrimary, true, true, false> : trace_kernel<kCount, kPrimary, true, false, false>;
     return wide ? trace_kernel<kCount, kPrimary, false, true, false> : trace_kernel<kCount, kPrimary, false, false, false>;
@@ -318,8 +415,8 @@ TraceKernel trace_variant(bool deep, bool wide, bool regroup) {
 
 TraceKernel trace_variant(const crt_ctx* ctx, bool counted, bool primary) {
     const bool wide = ctx->S.node_count > 64;      // two mask words: 65 to 128 nodes, or groups of nodes beyond that
-    if (primary) return trace_variant<false, true>(ctx->deep, wide, ctx->regroup);
-    return counted ? trace_variant<true, false>(ctx->deep, wide, ctx->regroup) : trace_variant<false, false>(ctx->deep, wide, ctx->regroup);
+    if (primary) return trace_variant<false, true>(ctx->deep, wide, ctx->regroup, ctx->tlas);
+    return counted ? trace_variant<true, false>(ctx->deep, wide, ctx->regroup, ctx->tlas) : trace_variant<false, false>(ctx->deep, wide, ctx->regroup, ctx->tlas);
 }
 
 void launch_trace(crt_ctx* ctx, bool counted, bool primary, uint32_t grid, hipStream_t stream, const DevPartition& P, int samples, const uint32_t* jump,
@@ -366,6 +463,12 @@ void crt_destroy(crt_ctx* ctx) {
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
     }
     delete ctx;
+}
+
+int crt_set_tlas(crt_ctx* ctx, int enable) {
+    if (!ctx) return CRT_E_INVALID;
+    ctx->want_tlas = enable != 0;
+    return CRT_OK;
 }
 
 int crt_device_count(int* count) {
@@ -449,7 +552,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
             return rec_of[i];
         };
         for (uint32_t i = 0; i < nn; i++) {
-            if (B.leaf[i]) { if (B.elem_count[i] > 15) return fail(ctx, CRT_E_LIMIT, "BVH leaf with more than 15 elements"); continue; }
+            if (B.leaf[i]) { if (B.elem_count[i] > kLeafMost) return fail(ctx, CRT_E_LIMIT, "BVH leaf with more than 13 elements"); continue; }
             BoxPair p{};
             const uint32_t l = B.left[i], r = B.right[i];
             set_box(p.a, &B.box[6 * l], &B.box[6 * l + 3]);
@@ -459,6 +562,10 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         }
         mesh_root[m] = nn ? ref_of(0) : make_leaf_ref(tri_base, 0);
     }
+    // ---- opt-in: a BVH over the object nodes in place of the reference's node scans (trace.cu:51, 166)
+    ctx->tlas = crt::knob_value(getenv("CRT_TLAS"), ctx->want_tlas ? 1 : 0, 0, 1) != 0;
+    uint32_t tlas_root = make_leaf_ref(0, 0), tlas_depth = 0;
+    if (ctx->tlas) tlas_build(d, pairs, tlas_root, tlas_depth);
     if (pairs.size() >= 0x80000000ull) return fail(ctx, CRT_E_LIMIT, "too many BVH nodes");
 
     std::vector<NodeXf> xf(N);
@@ -468,8 +575,8 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         xf[i].mesh_id = n.object_kind == CRT_OBJ_MESH ? n.mesh_id : -1;
         xf[i].root_ref = n.object_kind == CRT_OBJ_MESH ? mesh_root[n.mesh_id] : 0;
         xf[i].material_id = n.material_id;
-        xf[i].flags = 0;
-        if (n.object_kind == CRT_OBJ_MESH) xf[i].flags = (d->meshes[n.mesh_id].nvn > 0 ? kXfHasNormals : 0u) | (d->meshes[n.mesh_id].nvt > 0 ? kXfHasTex : 0u);
+        xf[i].flags = (uint32_t)n.object_kind << kXfKindShift;
+        if (n.object_kind == CRT_OBJ_MESH) xf[i].flags |= (d->meshes[n.mesh_id].nvn > 0 ? kXfHasNormals : 0u) | (d->meshes[n.mesh_id].nvt > 0 ? kXfHasTex : 0u);
     }
 
     std::vector<DevTexture> textures(d->texture_count);
@@ -520,7 +627,9 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // nodes 11 + 5 is the better split, without any mesh (spheres and planes only: a query is a few NODE turns) 9 + 7
     // (measured over the fixture scenes; any split computes the same image).
     const uint32_t kLdsLimit = 141 * 1024, kLdsLimitDeep = 150 * 1024;
-    const uint32_t stack_total = max_depth + 2;
+    // (BVH over the nodes: its own levels, the marker under a mesh walk, then the mesh's levels)
+    const uint32_t stack_total = max_depth + 2 + (ctx->tlas ? tlas_depth + 2 : 0);
+    S.tlas_root = tlas_root;
     {
         const uint32_t usual = CRT_BLOCK / 64 * 12 / 16;
         uint32_t mesh_nodes = 0;
@@ -540,7 +649,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     const uint32_t fit = kLdsLimit / lane_bytes, fit_deep = kLdsLimitDeep / lane_bytes;
     // Trees that the plain LDS stack holds run the regrouping kernels; a tree too deep for it is bound by memory
     // latency, and there the kernels for deep trees (more queries in flight, 23 stack entries in LDS) are faster.
-    ctx->regroup = crt::knob_value(getenv("CRT_REGROUP"), stack_total <= fit ? 1 : 0, 0, 1) != 0;
+    ctx->regroup = ctx->tlas || crt::knob_value(getenv("CRT_REGROUP"), stack_total <= fit ? 1 : 0, 0, 1) != 0;
     if (ctx->regroup) {
         // Regrouping kernels: 13 of the 16 waves traverse, and the last S.swing_waves of those take shading turns when the
         // shading queues run long, so one split serves scenes with much and with little to walk through.
@@ -645,6 +754,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         }
         S.drift_rel = (float)rel * 1.000001f; S.drift_abs = (float)abs_ * 1.000001f;
         if (const char* e = getenv("CRT_NO_SCAN_MASK")) if (atoi(e) != 0) S.scan_mask = 0;
+        if (ctx->tlas) S.scan_mask = 0;      // nothing is scanned
         // profiling only: the counted build then scans by the mask too (its node counters no longer match the reference's)
         if (const char* e = getenv("CRT_COUNTED_BY_MASK")) if (atoi(e) != 0 && S.scan_mask) S.scan_mask = 3;
     }

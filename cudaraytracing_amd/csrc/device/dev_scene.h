@@ -44,6 +44,8 @@ CRT_HD uint32_t make_leaf_ref(uint32_t start, uint32_t count) { return kRefLeaf 
 CRT_HD bool ref_is_leaf(uint32_t r) { return (r & kRefLeaf) != 0; }
 CRT_HD uint32_t leaf_start(uint32_t r) { return r & 0x07ffffffu; }
 CRT_HD uint32_t leaf_count(uint32_t r) { return (r >> 27) & 0xfu; }
+constexpr uint32_t kLeafMost = 13u;                       // triangles in a BVH leaf, at most; the two counts above it mark
+constexpr uint32_t kTlasLeave = 14u, kTlasEnter = 15u;    // references of the BVH over scene nodes (DevScene::tlas_root)
 
 // Scene-node half of a box pair: ref = object kind (2 bits) | (index of the
 // first node after this node's subtree << 2); aux unused.
@@ -74,10 +76,10 @@ struct alignas(16) NodeXf {
     uint32_t root_ref;  // mesh: BVH root reference
     int32_t mesh_id;
     int32_t material_id;
-    uint32_t flags;     // mesh: kXfHasNormals | kXfHasTex
+    uint32_t flags;     // mesh: kXfHasNormals | kXfHasTex; bits 2..3: the node's object kind
 };
 static_assert(sizeof(NodeXf) == 112, "NodeXf layout");
-constexpr uint32_t kXfHasNormals = 1u, kXfHasTex = 2u;
+constexpr uint32_t kXfHasNormals = 1u, kXfHasTex = 2u, kXfKindShift = 2u;
 
 struct DevTexture {
     uint32_t width, height;
@@ -144,6 +146,11 @@ struct DevScene {
     uint32_t scan_mask;              // bit 0: a candidate mask is in use (small drift); bit 1: the counting build follows it too (profiling); bit 2: its bits are groups of nodes
     uint32_t group_shift, group_count;
     float drift_rel, drift_abs;
+    // Opt-in mode that does not reproduce the reference's node order: a BVH over the world boxes of the object nodes
+    // takes the place of the scan.  Its interior records lie among the box pairs; a child reference with leaf count
+    // kTlasEnter names a scene node to enter (in the start field), one with kTlasLeave on the stack marks where a
+    // query that walks a mesh returns to world space.
+    uint32_t tlas_root;
     const BoxPair* group_pairs;
     const BoxPair* pairs;
     const TriRec* tris;

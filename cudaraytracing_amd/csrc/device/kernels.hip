@@ -141,14 +141,21 @@ DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 // (min, max) pair of one axis: subtraction and multiplication run as two-float packed instructions
 // (v_pk_add_f32 / v_pk_mul_f32), which round each half exactly like the scalar forms.
 typedef float f2 __attribute__((ext_vector_type(2)));
-DEV bool slab(f2 bx, f2 by, f2 bz, f3 pos, f3 inv, float tmax, float& dist) {
+// (enter: where the ray enters the box, negative for a ray that starts inside it - the reference reports the way OUT
+// as that ray's distance, and culls by it)
+DEV bool slab(f2 bx, f2 by, f2 bz, f3 pos, f3 inv, float tmax, float& dist, float& enter) {
     const f2 tx = (bx - pos.x) * inv.x, ty = (by - pos.y) * inv.y, tz = (bz - pos.z) * inv.z;
     const float cx = fminf(tx.x, tx.y), cy = fminf(ty.x, ty.y), cz = fminf(tz.x, tz.y);
     const float fx = fmaxf(tx.x, tx.y), fy = fmaxf(ty.x, ty.y), fz = fmaxf(tz.x, tz.y);
     const float tEnter = fmaxf(cx, fmaxf(cy, cz));
     const float tExit = fminf(fx, fminf(fy, fz));
     dist = tEnter >= -FLT_EPSILON ? tEnter : tExit;
+    enter = tEnter;
     return (tEnter >= -FLT_EPSILON || tExit >= -FLT_EPSILON) && tEnter <= tExit && tEnter <= tmax;
+}
+DEV bool slab(f2 bx, f2 by, f2 bz, f3 pos, f3 inv, float tmax, float& dist) {
+    float enter;
+    return slab(bx, by, bz, pos, inv, tmax, dist, enter);
 }
 
 // Node::ToLocal / FromLocal for a whole ray (scene/scene.cuh:150-189): x, y, z hold (position, direction) pairs;
@@ -593,13 +600,16 @@ DEV bool queue_pop(uint32_t* head, const uint32_t* tail, const ring_t* ring, boo
 // kRegroup: queries, not lanes, own traversal state.  A query in flight has a context in LDS (its stack column and a
 // 112-byte record); a wave keeps the queries that wait for the operation it is running in its lanes' registers and
 // parks the others in the ring of the operation they wait for, where the waves that run that operation pick them up.
-template <bool kCount, bool kPrimary, bool kDeep, bool kWide, bool kRegroup>
+// kTlas (an opt-in mode of the regrouping kernel whose images are not the reference's bit for bit): queries walk a BVH
+// over the scene's object nodes instead of scanning the node list; objects are met in the order of the walk.
+template <bool kCount, bool kPrimary, bool kDeep, bool kWide, bool kRegroup, bool kTlas = false>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(DevScene S, DevPartition P, int samples,
                                                              const uint32_t* __restrict__ jump,
                                                              uint32_t* __restrict__ queue, DevStats* __restrict__ stats,
                                                              int32_t* __restrict__ out_node, int32_t* __restrict__ out_face,
                                                              float* __restrict__ out_t, uint32_t* slot_mem) {
     static_assert(!(kDeep && kRegroup), "the regrouping kernel keeps the top of every stack in LDS already");
+    static_assert(!kTlas || (kRegroup && !kWide), "the walk over a BVH of the nodes is a mode of the regrouping kernel and uses no candidate mask");
     extern __shared__ uint32_t lds[];
     __shared__ BlockCtl ctl;
     constexpr uint32_t kQLog = kDeep ? kDeepQueueLog : kQueueLog, kQSize = 1u << kQLog;      // ring of slots; slots per block <= kQSize
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const bool by_mask = follow_mask && !grouped;
     const bool by_group = follow_mask && grouped;
     // the first step of a query's scan is taken by the shading wave that sets the query up (write_query)
-    constexpr bool kFirstStepHere = !kCount && !kWide;
+    constexpr bool kFirstStepHere = !kCount && !kWide && !kTlas;
     const uint32_t group_shift = S.group_shift;
 
     Tally tally = {};
@@ -760,6 +770,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 L.h_a = __uint_as_float(c.x); L.h_b = __uint_as_float(c.y); L.h_c = c.z;
             }
             begin = walk_ended();
+        }
+        // the walk over the BVH of the nodes starts at its root: an interior record, the only object of the scene, or nothing
+        if (kTlas) {
+            L.entered = 0; L.sp = 0; L.lo = 0; L.top = 0; L.mesh_hit = false; L.more = false;
+            const uint32_t r = S.tlas_root;
+            if (!ref_is_leaf(r)) { L.cur = r; begin = S_BOX; }
+            else if (leaf_count(r) == kTlasEnter) { L.pend = r; begin = S_NODE; }
+            else begin = query_done();
         }
         return begin;
     };
@@ -908,7 +926,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     auto resolve = [&](bool have_next, uint32_t next_ref, float next_t) -> uint32_t {
         for (;;) {
             if (!have_next) {
-                if (L.sp == 0) return walk_ended();
+                if (L.sp == 0) return kTlas ? query_done() : walk_ended();
                 stack_pop(next_ref, next_t);
             }
             have_next = false;
@@ -916,6 +934,11 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             if (!ref_is_leaf(next_ref)) { L.cur = next_ref; return S_BOX; }
             TALLY(bvh_leaves);
             if (leaf_count(next_ref) == 0) continue;
+            // (BVH of the nodes: an object to enter, or the end of a mesh walk - the ray goes back to world space)
+            if (kTlas && leaf_count(next_ref) >= kTlasLeave) {
+                L.pend = leaf_count(next_ref) == kTlasLeave ? kPendExit : next_ref;
+                return S_NODE;
+            }
             L.pend = next_ref;
             return S_LEAF;
         }
@@ -927,9 +950,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
         const uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
         float tA = CRT_BIGFLOAT, tB = CRT_BIGFLOAT;
-        float dA, dB;
-        const bool hitA = slab(f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, L.qpos(), L.qinv, L.limit, dA);
-        const bool hitB = slab(f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, L.qpos(), L.qinv, L.limit, dB);
+        float dA, dB, eA, eB;
+        const bool hitA = slab(f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, L.qpos(), L.qinv, L.limit, dA, eA);
+        const bool hitB = slab(f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, L.qpos(), L.qinv, L.limit, dB, eB);
+        // This mode goes by the distance at which a ray ENTERS a box, for the boxes over the nodes and for those inside a
+        // mesh alike.  (The reference's box test reports the way OUT for a ray that starts inside a box; its node scan skips
+        // a node, and its BVH walk a subtree, when that distance lies beyond the closest hit so far - trace.cu:57-59,
+        // objects.cu:190-192 - so what it finds depends on the order of the nodes, which this mode does not keep.)
+        if (kTlas) { dA = eA; dB = eB; }
         if (hitA) tA = dA;
         if (hitB) tB = dB;
         TALLY(bvh_interior);
@@ -948,6 +976,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
         const float far_t = fmaxf(tA, tB);
         bool keep = any && (L.shadow || !(L.hz < far_t));
         if (!kCount || follow_mask) keep = keep && ((hitA && hitB) || ref_is_leaf(a_near ? ref_b : ref_a));      // (counting build: only when profiling the plain kernels' walk)
+        if (kTlas) keep = keep && hitA && hitB;      // (a leaf whose box is missed is left out too: an object, or triangles that cannot be hit)
         stack_push(a_near ? ref_b : ref_a, far_t, keep);
         return resolve(any, a_near ? ref_a : ref_b, fminf(tA, tB));
     };
@@ -1015,6 +1044,52 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     // Node::ToLocal, then the sphere / plane test in place or the start of a BVH walk (trace.cu:61-66, 188-191;
     // objects.cu:7-159).
     auto op_node = [&]() -> uint32_t {
+        if (kTlas) {
+            // Walk over the BVH of the nodes: the turn either takes the query into the object of one node (Node::ToLocal,
+            // then the sphere / plane test in place or the start of the mesh's BVH walk under a marker on the stack) or,
+            // when that marker comes off the stack, back out of the mesh (Node::FromLocal, world position of a hit).
+            const bool leaving = L.pend == kPendExit;
+            const uint32_t idx = leaving ? L.entered : (leaf_start(L.pend) < node_count ? leaf_start(L.pend) : 0u);
+            const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
+            const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r3 = xp[3], r4 = xp[4], r5 = xp[5], r6 = xp[6];
+            const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
+            L.pend = 0;
+            if (leaving) {
+                if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
+                L.mesh_hit = false;
+                xform_ray(tm, L.pdx, L.pdy, L.pdz);
+                L.qinv = recip3(L.qdir());
+                return resolve(false, 0, 0);
+            }
+            const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            const uint32_t kind = (__float_as_uint(r6.w) >> kXfKindShift) & 3u;
+            TALLY(node_enters);
+            if (kind == CRT_OBJ_MESH) {
+                xform_ray(itm, L.pdx, L.pdy, L.pdz);
+                L.qinv = recip3(L.qdir());
+                L.entered = idx; L.mesh_hit = false;
+                stack_push(make_leaf_ref(0, kTlasLeave), -CRT_BIGFLOAT, true);
+                return resolve(true, __float_as_uint(r6.x), 0.0f);
+            }
+            // sphere / plane: tested with a local copy of the ray, the query's own ray stays in world space
+            f2 px = L.pdx, py = L.pdy, pz = L.pdz;
+            xform_ray(itm, px, py, pz);
+            const f3 pos = mk3(px.x, py.x, pz.x), dir = mk3(px.y, py.y, pz.y);
+            if (kind == CRT_OBJ_SPHERE) TALLY(sphere_tests); else TALLY(plane_tests);
+            bool front;
+            float t;
+            const bool got = (kind == CRT_OBJ_SPHERE || kind == CRT_OBJ_PLANE) && unit_object_hit(kind == CRT_OBJ_SPHERE, pos, dir, L.shadow, L.limit, L.hz, t, front);
+            if (got) {
+                if (L.shadow) return shadow_blocked();
+                const f3 p = pos + t * dir;
+                L.hz = t;
+                L.hpos = xform_point(tm, p);
+                L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
+                L.h_node = idx; L.h_front = front;
+                L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
+            }
+            return resolve(false, 0, 0);
+        }
         // Which node is looked at does not depend on the way back, so the forward matrix of the node being left and
         // the box record of the next node are fetched together (lanes that leave nothing read the record of node 0,
         // one address for all of them).
@@ -1152,7 +1227,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 uint4* r4 = reinterpret_cast<uint4*>(rec);
                 const f3 qp = L.qpos(), qd = L.qdir();
                 // last word: 0, or the node whose space the ray (and a hit found in it) is still in: node + 1, bit 31 = hit found there
-                const uint32_t inside = L.pend == kPendExit ? ((L.entered + 1u) | (L.mesh_hit ? 0x80000000u : 0u)) : 0u;
+                const uint32_t inside = !kTlas && L.pend == kPendExit ? ((L.entered + 1u) | (L.mesh_hit ? 0x80000000u : 0u)) : 0u;
                 r4[0] = uint4{L.pk | (paired ? kPkPaired : 0u), __float_as_uint(L.hz), L.h_kind | (L.h_front ? 4u : 0u) | (L.h_node << 3), L.h_c};
                 r4[1] = uint4{__float_as_uint(L.hpos.x), __float_as_uint(L.hpos.y), __float_as_uint(L.hpos.z), __float_as_uint(L.h_a)};
                 r4[2] = uint4{__float_as_uint(qp.x), __float_as_uint(qp.y), __float_as_uint(qp.z), __float_as_uint(L.h_b)};

@@ -20,6 +20,12 @@ class Context:
         if rc != capi.OK:
             raise capi.CrtError(rc, capi.lib().crt_last_error(self._h).decode(errors="replace"))
 
+    def set_tlas(self, enable=True):
+        """From the next upload on, queries walk a BVH over the scene's object nodes instead of the reference's
+        node scan (renderer/trace.cu:51, 166).  Faster on scenes of many nodes; images are no longer the
+        reference's bit for bit."""
+        self._check(capi.lib().crt_set_tlas(self._h, 1 if enable else 0))
+
     def upload(self, scene):
         d = scene.desc()
         self._check(capi.lib().crt_upload_scene(self._h, C.byref(d)))

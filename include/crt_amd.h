@@ -193,6 +193,14 @@ int crt_device_count(int* count);
 
 int crt_create(int device, crt_ctx** out);
 void crt_destroy(crt_ctx* ctx);
+
+/* Opt-in acceleration that does NOT reproduce the reference's images bit for bit: from the next crt_upload_scene
+ * on, ray queries walk a BVH over the world boxes of the scene's object nodes instead of scanning the node list
+ * from end to end (renderer/trace.cu:51 closest hit, :166 shadow rays).  Objects are then met in the order of that
+ * walk rather than in node order: among hits at exactly the same distance another one may win, and a ray goes
+ * through the ToLocal / FromLocal round trips of other nodes, so last bits differ.  For scenes of many nodes
+ * (instances); off by default.  The environment variable CRT_TLAS=0/1, read at upload, overrides the call. */
+int crt_set_tlas(crt_ctx* ctx, int enable);
 const char* crt_last_error(const crt_ctx* ctx);
 
 /* Copy the scene to the device: builds one BVH per mesh on the host, re-lays

@@ -261,7 +261,7 @@ struct Box {
     }
     void operator+=(const Box box) { *this += box.pmin; *this += box.pmax; }
     // the Ray and ShadowRay overloads are the same arithmetic (rays.cuh:138-187)
-    bool Intersect(const float3& rpos, const float3& rdir, float& dist, const float t_max) const {
+    bool Intersect(const float3& rpos, const float3& rdir, float& dist, const float t_max, float* enter = nullptr) const {
         const float3 inv = mk(1.0f / rdir.x, 1.0f / rdir.y, 1.0f / rdir.z);
         const float3 tLow = (pmin - rpos) * inv;
         const float3 tHigh = (pmax - rpos) * inv;
@@ -269,6 +269,7 @@ struct Box {
         const float3 tFar = mk(fmaxf(tLow.x, tHigh.x), fmaxf(tLow.y, tHigh.y), fmaxf(tLow.z, tHigh.z));
         const float tEnter = fmaxf(tClose.x, fmaxf(tClose.y, tClose.z));
         const float tExit = fminf(tFar.x, fminf(tFar.y, tFar.z));
+        if (enter) *enter = tEnter;
         if ((tEnter >= -FLT_EPSILON || tExit >= -FLT_EPSILON) && tEnter <= tExit && tEnter <= t_max) {
             dist = tEnter >= -FLT_EPSILON ? tEnter : tExit;
             return true;
@@ -604,6 +605,16 @@ static bool PlaneIntersectShadowRay(const ShadowRay& ray, const float tMax, cons
     return true;
 }
 
+// NOT the reference's rule, and off unless a test switches it on (oracle_set_node_cull): the node scan culls a node
+// by the distance at which the ray ENTERS the node's box.  The reference culls by the distance its box test reports,
+// which for a ray that starts inside the box is the way out (rays.cuh:156, trace.cu:59): a node around the ray's origin
+// is skipped whenever an earlier node of the list was hit nearer than that way out, whatever the node itself holds,
+// and the BVH walk inside a mesh drops boxes around the origin by the same measure (objects.cu:190-192), so what a
+// ray finds depends on the order in which the nodes are visited.
+// The switch states the one rule by which the product's opt-in BVH over the nodes departs from the reference on
+// purpose, so that a test can tell that departure from a defect.
+static std::atomic<int> g_cull_by_entry(0);
+
 #define BVH_MAX_DEPTH 64
 
 bool Mesh::Traverse(Ray const& ray, Hit& hit, const int hitSide) const {
@@ -627,8 +638,13 @@ bool Mesh::Traverse(Ray const& ray, Hit& hit, const int hitSide) const {
         const size_t leftID = nodes[top.node].leftChild;
         const size_t rightID = nodes[top.node].rightChild;
         float tLeft = BIGFLOAT, tRight = BIGFLOAT;
-        const bool hitLeft = nodes[leftID].box.Intersect(ray.pos, ray.dir, tLeft, BIGFLOAT);
-        const bool hitRight = nodes[rightID].box.Intersect(ray.pos, ray.dir, tRight, BIGFLOAT);
+        float eLeft = 0, eRight = 0;
+        const bool hitLeft = nodes[leftID].box.Intersect(ray.pos, ray.dir, tLeft, BIGFLOAT, &eLeft);
+        const bool hitRight = nodes[rightID].box.Intersect(ray.pos, ray.dir, tRight, BIGFLOAT, &eRight);
+        if (g_cull_by_entry.load(std::memory_order_relaxed)) {      // (not the reference's rule: see g_cull_by_entry)
+            if (hitLeft) tLeft = eLeft;
+            if (hitRight) tRight = eRight;
+        }
         if (!hitLeft && !hitRight) continue;
         const size_t closeID = tLeft <= tRight ? leftID : rightID;
         const size_t farID = tLeft <= tRight ? rightID : leftID;
@@ -907,7 +923,9 @@ static bool TraceThroughScene(const Scene& sc, Ray& ray, Hit& hit) {
         if (node->objectKind != OBJ_NONE) {
             float boxZ = BIGFLOAT;
             COUNT(node_box_tests);
-            const bool hitBox = node->boundingBox.Intersect(ray.pos, ray.dir, boxZ, BIGFLOAT);
+            float enterZ = 0;
+            const bool hitBox = node->boundingBox.Intersect(ray.pos, ray.dir, boxZ, BIGFLOAT, &enterZ);
+            if (hitBox && g_cull_by_entry.load(std::memory_order_relaxed)) boxZ = enterZ;
             if (hitBox && boxZ < hit.z) {
                 COUNT(node_enters);
                 node->ToLocal(ray.pos, ray.dir);
@@ -1165,6 +1183,8 @@ static Scene* load_scene_file(const char* path) {
 
 // ------------------------------------------------ C entry points (ctypes)
 extern "C" {
+
+void oracle_set_node_cull(int by_entry) { g_cull_by_entry.store(by_entry ? 1 : 0); }
 
 void* oracle_scene_load(const char* path) { seqjump_init(); return load_scene_file(path); }
 void oracle_scene_free(void* h) { delete (Scene*)h; }

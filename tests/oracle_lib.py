@@ -39,6 +39,7 @@ def load(flavour="det"):
         L.oracle_seqjump_matrix.argtypes = [C.c_uint32, C.c_void_p]
         L.oracle_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_libm_is_glibc.restype = C.c_int
+        L.oracle_set_node_cull.argtypes = [C.c_int]
         _libs[flavour] = L
     return _libs[flavour]
 
@@ -117,6 +118,12 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+
+def set_node_cull(by_entry, flavour="det"):
+    """by_entry: the node scan culls by where a ray enters a node's box - not the reference's rule (see oracle.cpp);
+    only for telling the declared departure of the product's opt-in BVH over the nodes from a defect."""
+    load(flavour).oracle_set_node_cull(1 if by_entry else 0)
 
 
 def convert(results, srgb, pass_mul, flavour="det"):
