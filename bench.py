@@ -145,7 +145,9 @@ def parse_args():
     ap.add_argument("--copies", type=int, default=1582, help="config 5: teapot copies")
     ap.add_argument("--cpu-spp", type=int, default=24, help="samples per pixel of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-counters", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="default run only: leave out the short run of the ten-million-triangle configuration")
+    ap.add_argument("--no-secondary", action="store_true", help="default run only: leave out the short runs of the ten-million-triangle configuration and of the many-node scene")
+    ap.add_argument("--tlas", action="store_true", help="walk a BVH over the scene nodes instead of the reference's node scan (crt_set_tlas): NOT bit-exact, "
+                                                        "reported with \"parity\": false and without the roofline pricing of the parity walk")
     return ap.parse_args()
 
 
@@ -177,6 +179,7 @@ def run_workload(args, headline, rank, world, local_rank, device, coll_device, r
     progress(f"scene ready: {scene_label}; uploading (BVH build, re-layout, copy to the device)")
     t0 = time.perf_counter()
     ctx = crt.Context(local_rank)
+    ctx.set_tlas(args.tlas)
     ctx.upload(scene)                      # BVH build + re-layout + H2D, outside the timed region
     upload_ms = (time.perf_counter() - t0) * 1e3
     ctx.set_partition(rank, world, STRIP_ROWS)
@@ -250,7 +253,7 @@ def run_workload(args, headline, rank, world, local_rank, device, coll_device, r
     per_rank = per_rank.cpu().tolist()
 
     roofline = None
-    if rank == 0 and not args.no_roofline_counters:
+    if rank == 0 and not args.no_roofline_counters and not args.tlas:
         roofline = price_roofline(args, ctx, scene, synthetic, headline, world, rank, k_ms, len(kernel_ms), ms_per_step)
 
     if rehearsal and rank == 0 and world > 1:
@@ -297,7 +300,7 @@ def run_workload(args, headline, rank, world, local_rank, device, coll_device, r
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic scene generated from the reference's teapot mesh, fixed seeds" if synthetic else "reference scene file (baked), fixed seeds",
             "config": {"workload": f"{scene_label} at {W}x{H}, {args.spp} spp in 1 pass, path-traced GI" + (f" ({cfg_name})" if headline else " (not a BASELINE.json configuration)"),
-                       "scene": args.scene, "width": W, "height": H, "spp": args.spp, "passes": 1,
+                       "scene": args.scene, "width": W, "height": H, "spp": args.spp, "passes": 1, "parity": not args.tlas,
                        "parallelism": f"{STRIP_ROWS}-row image strips round-robin over {world} GPU(s), scene replicated, RGB8 rows gathered to rank 0"},
             "rays_per_frame": rays_per_frame, "closest_rays": float(rays[1].item()), "shadow_rays": float(rays[2].item()),
             "frame_includes": "accumulator clear, trace kernel, ConvertColors, row gather, D2H of the 8-bit image",
@@ -390,6 +393,68 @@ def price_roofline(args, ctx, scene, synthetic, headline, world, rank, k_ms, lau
     return roofline
 
 
+def many_nodes_workload(local_rank, n_side=40, width=1280, height=720, spp=16, frames=2):
+    """A scene of n_side^2 + 2 nodes (instances of one small mesh over a floor; cudaraytracing_amd/synthetic.py): kernel
+    time of the bit-exact scan (by groups of nodes) beside the opt-in walk over a BVH of the nodes, which is not
+    bit-exact - its distance from the CPU oracle is measured here on a reduced image and stated with it."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from cudaraytracing_amd.synthetic import instance_grid_xml
+
+    def psnr(a, b):
+        mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+        return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        scene = crt.Scene.load_xml(instance_grid_xml(tmp, n_side), tmp)
+        nodes = int(scene.desc().node_count)
+        small_w, small_h, small_spp = 256, 144, 4
+        scene.set_resolution(small_w, small_h)
+        flat = os.path.join(tmp, "grid.crtscene")
+        scene.save_file(flat)
+        o = orc.OracleScene(flat)
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        progress(f"many-node scene ({nodes} nodes): oracle images at {small_w}x{small_h}, {small_spp} spp")
+        want = orc.convert(o.render(0, small_spp, threads=threads)[0], o.srgb, 1.0)
+        orc.set_node_cull(True)
+        try:
+            want_entry = orc.convert(o.render(0, small_spp, threads=threads)[0], o.srgb, 1.0)
+        finally:
+            orc.set_node_cull(False)
+        o.close()
+    lines = {}
+    for mode in ("scan", "tlas"):
+        ctx = crt.Context(local_rank)
+        ctx.set_tlas(mode == "tlas")
+        scene.set_resolution(small_w, small_h)
+        ctx.upload(scene)
+        ctx.render_pass(0, small_spp)
+        ctx.convert(1.0, scene.srgb)
+        small = ctx.read_image()
+        scene.set_resolution(width, height)
+        ctx.upload(scene)
+        ctx.render_pass(0, spp)
+        ctx.kernel_times()
+        for _ in range(frames):
+            ctx.clear()
+            ctx.render_pass(0, spp)
+        ms = float(np.mean(ctx.kernel_times()))
+        st = ctx.stats()
+        rays = st["closest_rays"] + st["shadow_rays"]
+        lines[mode] = {"kernel_ms": ms, "value": rays / ms * 1e-3, "unit": "Mrays/s", "rays_per_frame": rays,
+                       "psnr_vs_oracle_db": psnr(small, want), "identical_to_oracle": bool((small == want).all())}
+        if mode == "tlas":
+            lines[mode]["psnr_vs_oracle_culling_by_entry_db"] = psnr(small, want_entry)
+        ctx.close()
+    lines["tlas"]["config"] = {"parity": False, "workload": f"{nodes}-node instance grid at {width}x{height}, {spp} spp, BVH over the nodes (crt_set_tlas)"}
+    lines["scan"]["config"] = {"parity": True, "workload": f"{nodes}-node instance grid at {width}x{height}, {spp} spp, node scan by groups of nodes"}
+    return {"scan": lines["scan"], "tlas": lines["tlas"], "frames_timed": frames,
+            "psnr_sample": f"8-bit images at {small_w}x{small_h}, {small_spp} spp, equal seeds, against the CPU oracle (as the reference has it, and with its "
+                           "node and BVH culling switched from the box test's reported distance to the entry distance: the one rule the walk departs from on purpose)",
+            "note": "kernel time only (no convert, no copy); the scan renders the oracle's image bit for bit, the walk does not and says so"}
+
+
 def main():
     args = parse_args()
     headline = fill_defaults(args)
@@ -420,7 +485,7 @@ def main():
     # The default single-GPU run also witnesses the other BASELINE configuration that fits one GPU, in short form: the
     # ten-million-triangle scene at 4K and 256 spp, one frame after the first one (scene generation and upload take
     # ~15 s, a frame ~3 s).
-    if out is not None and world == 1 and args.config == 3 and headline and not args.no_secondary:
+    if out is not None and world == 1 and args.config == 3 and headline and not args.no_secondary and not args.tlas:
         progress("secondary workload: BASELINE.json configs[4] (one timed frame)")
         sec_args = argparse.Namespace(**vars(args))
         sec_args.config, sec_args.scene, sec_args.width, sec_args.height, sec_args.spp = 5, None, None, None, None
@@ -430,6 +495,8 @@ def main():
         keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "first_frame_ms", "first_frame_kernel_ms", "dtype", "data", "config",
                 "rays_per_frame", "scene_upload_ms", "roofline")
         out["secondary"] = {k: sec[k] for k in keep}
+        progress("many-node scene: node scan beside the opt-in BVH over the nodes")
+        out["many_nodes"] = many_nodes_workload(local_rank)
 
     if out is not None:
         print(json.dumps(out))

@@ -6,7 +6,7 @@ TAG=${1:-r1}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-ARGS="--steps 2 --warmup 1 --cpu-spp 0 --no-roofline-counters $*"
+ARGS="--steps 2 --warmup 1 --cpu-spp 0 --no-roofline-counters --no-secondary $*"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, rocprof options...
   local name=$1; shift
