@@ -1051,44 +1051,52 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const bool leaving = L.pend == kPendExit;
             const uint32_t idx = leaving ? L.entered : (leaf_start(L.pend) < node_count ? leaf_start(L.pend) : 0u);
             const float4* __restrict__ xp = reinterpret_cast<const float4*>(S.xf + idx);
-            const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r3 = xp[3], r4 = xp[4], r5 = xp[5], r6 = xp[6];
-            const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
             L.pend = 0;
+            // (one copy of the pop loop behind all three cases: what differs is whether there is a node to go on with)
+            bool have_next = false;
+            uint32_t next_ref = 0;
             if (leaving) {
+                const float4 r3 = xp[3], r4 = xp[4], r5 = xp[5];
+                const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
                 if (L.mesh_hit) L.hpos = xform_point(tm, L.qpos() + L.hz * L.qdir());
                 L.mesh_hit = false;
                 xform_ray(tm, L.pdx, L.pdy, L.pdz);
                 L.qinv = recip3(L.qdir());
-                return resolve(false, 0, 0);
+            } else {
+                const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2], r6 = xp[6];
+                const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                const uint32_t kind = (__float_as_uint(r6.w) >> kXfKindShift) & 3u;
+                TALLY(node_enters);
+                f2 px = L.pdx, py = L.pdy, pz = L.pdz;
+                xform_ray(itm, px, py, pz);
+                if (kind == CRT_OBJ_MESH) {
+                    L.pdx = px; L.pdy = py; L.pdz = pz;
+                    L.qinv = recip3(L.qdir());
+                    L.entered = idx; L.mesh_hit = false;
+                    stack_push(make_leaf_ref(0, kTlasLeave), -CRT_BIGFLOAT, true);
+                    have_next = true; next_ref = __float_as_uint(r6.x);
+                } else {
+                    // sphere / plane: tested with a local copy of the ray, the query's own ray stays in world space
+                    const f3 pos = mk3(px.x, py.x, pz.x), dir = mk3(px.y, py.y, pz.y);
+                    if (kind == CRT_OBJ_SPHERE) TALLY(sphere_tests); else TALLY(plane_tests);
+                    bool front;
+                    float t;
+                    const bool got = (kind == CRT_OBJ_SPHERE || kind == CRT_OBJ_PLANE) && unit_object_hit(kind == CRT_OBJ_SPHERE, pos, dir, L.shadow, L.limit, L.hz, t, front);
+                    if (got) {
+                        if (L.shadow) return shadow_blocked();
+                        const f3 p = pos + t * dir;
+                        // (the forward matrix is fetched only now: few of the objects a walk looks at are hit)
+                        const float4 r3 = xp[3], r4 = xp[4], r5 = xp[5];
+                        const float tm[12] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w};
+                        L.hz = t;
+                        L.hpos = xform_point(tm, p);
+                        L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
+                        L.h_node = idx; L.h_front = front;
+                        L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
+                    }
+                }
             }
-            const float itm[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-            const uint32_t kind = (__float_as_uint(r6.w) >> kXfKindShift) & 3u;
-            TALLY(node_enters);
-            if (kind == CRT_OBJ_MESH) {
-                xform_ray(itm, L.pdx, L.pdy, L.pdz);
-                L.qinv = recip3(L.qdir());
-                L.entered = idx; L.mesh_hit = false;
-                stack_push(make_leaf_ref(0, kTlasLeave), -CRT_BIGFLOAT, true);
-                return resolve(true, __float_as_uint(r6.x), 0.0f);
-            }
-            // sphere / plane: tested with a local copy of the ray, the query's own ray stays in world space
-            f2 px = L.pdx, py = L.pdy, pz = L.pdz;
-            xform_ray(itm, px, py, pz);
-            const f3 pos = mk3(px.x, py.x, pz.x), dir = mk3(px.y, py.y, pz.y);
-            if (kind == CRT_OBJ_SPHERE) TALLY(sphere_tests); else TALLY(plane_tests);
-            bool front;
-            float t;
-            const bool got = (kind == CRT_OBJ_SPHERE || kind == CRT_OBJ_PLANE) && unit_object_hit(kind == CRT_OBJ_SPHERE, pos, dir, L.shadow, L.limit, L.hz, t, front);
-            if (got) {
-                if (L.shadow) return shadow_blocked();
-                const f3 p = pos + t * dir;
-                L.hz = t;
-                L.hpos = xform_point(tm, p);
-                L.h_kind = kind == CRT_OBJ_SPHERE ? H_SPHERE : H_PLANE;
-                L.h_node = idx; L.h_front = front;
-                L.h_a = p.x; L.h_b = p.y; L.h_c = __float_as_uint(p.z);
-            }
-            return resolve(false, 0, 0);
+            return resolve(have_next, next_ref, 0.0f);
         }
         // Which node is looked at does not depend on the way back, so the forward matrix of the node being left and
         // the box record of the next node are fetched together (lanes that leave nothing read the record of node 0,
@@ -1764,7 +1772,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                     L.col = col;
                     const uint32_t begin = query_start(slot, w0, w1, w2, w3);
                     uint4* const c = ctx_words();
-                    c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6();
+                    c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); if (!kTlas) c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6();
                     state = begin;
                     direct = true;
                 }
@@ -1831,10 +1839,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 }
             } else {
                 const uint4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
-                get_c0(c0); get_c1(c1); get_c2(c2); get_c3(c3); get_c4(c4); get_c5(c5); get_c6(c6);
+                get_c0(c0); get_c1(c1); get_c2(c2); get_c3(c3); if (!kTlas) get_c4(c4); get_c5(c5); get_c6(c6);
                 if (active) {
                     state = op_node();
-                    c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6();
+                    c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); if (!kTlas) c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6();
                 }
             }
             if (kCount) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tally.cycles[kOp] += t - t_mark; t_mark = t; }
@@ -1921,7 +1929,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
                 get_c0(c0); get_c1(c1); get_c2(c2); get_c3(c3); get_c5(c5); get_c6(c6);
             }
             op_exchange();
-            if (took) { c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6(); }
+            if (took) { c[0] = put_c0(); c[1] = put_c1(); c[2] = put_c2(); c[3] = put_c3(); if (!kTlas) c[4] = put_c4(); c[5] = put_c5(); c[6] = put_c6(); }
             if (__ballot(state == S_IDLE) != waiting) fruitless = 0;
             if (kCount) tally.cycles[4] += __builtin_amdgcn_s_memtime() - t_start;
         }
