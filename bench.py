@@ -60,6 +60,7 @@ def kernel_source_digest():
     import hashlib, re
     h = hashlib.sha1()
     for rel in ("cudaraytracing_amd/csrc/device/kernels.hip", "cudaraytracing_amd/csrc/device/dev_scene.h",
+                "cudaraytracing_amd/csrc/device/api_device.hip",      # launch parameters and their defaults
                 "cudaraytracing_amd/csrc/crt_detmath.h", "cudaraytracing_amd/csrc/crt_vec.h"):
         with open(os.path.join(ROOT, rel), "r", encoding="utf-8", errors="replace") as f:
             text = f.read()

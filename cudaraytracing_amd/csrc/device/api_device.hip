@@ -659,7 +659,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         // a block has S.contexts query contexts, each with a stack column and 112 bytes of parked
         // state in LDS; the LDS left beside the rings decides how many stack entries a column holds (the top of the
         // stack; older entries move to device memory).
-        S.contexts = crt::knob_value(getenv("CRT_CONTEXTS"), 768, 64, kMaxContexts) & ~63u;
+        S.contexts = crt::knob_value(getenv("CRT_CONTEXTS"), 832, 64, kMaxContexts) & ~63u;
         ctx->deep = false;
         size_t fixed = 0;
         for (int variant = 0; variant < 3; variant++) {
@@ -689,7 +689,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.direct_start = crt::knob_value(getenv("CRT_DIRECT_START"), 1, 0, 1);
     S.swing_waves = crt::knob_value(getenv("CRT_SWING_WAVES"), 6, 0, 16);
     S.swing_fill = crt::knob_value(getenv("CRT_SWING_FILL"), 128, 1, 1u << 20);
-    S.burst_max = crt::knob_value(getenv("CRT_BURST_MAX"), 16, 1, 1u << 20);
+    S.burst_max = crt::knob_value(getenv("CRT_BURST_MAX"), 64, 1, 1u << 20);
     {
         // Drift bound of the scan's candidate mask.  One round trip through node j maps p to fl(tm * fl(itm * p)): its
         // distance from p is at most |R p + r| (R = tm3 * itm3 - I, r = tm3 * t_itm + t_tm: the stored matrices are
@@ -769,7 +769,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.sched_exchange_min = crt::knob_value(getenv("CRT_SCHED_EXCHANGE_MIN"), ctx->deep ? 16 : 12, 1, 64);
     S.first_step = crt::knob_value(getenv("CRT_FIRST_STEP"), 96, 0, 1u << 20);
     {
-        const uint32_t most = ctx->deep ? kMaxSlotsDeep : kMaxSlots, usual = ctx->deep ? 72 * S.trav_waves : 96 * S.trav_waves;
+        const uint32_t most = ctx->deep ? kMaxSlotsDeep : kMaxSlots, usual = ctx->deep ? 72 * S.trav_waves : (ctx->regroup ? 108 : 96) * S.trav_waves;
         S.slots = crt::knob_value(getenv("CRT_SLOTS"), usual < most ? usual : most, 64, most);
     }
     S.serve_batch_min = crt::knob_value(getenv("CRT_SERVE_BATCH_MIN"), 64, 1, 64);
