@@ -156,6 +156,26 @@ def test_counting_build_walks_the_same_way(tlas_ctx, tmp_path):
     assert st["bvh_interior"] > rays      # at least the root of the BVH over the nodes, per ray
 
 
+def test_walk_is_deterministic_and_partitions_like_the_scan(tlas_ctx, tmp_path):
+    """Not bit-exact against the reference, but exact against itself: a query's walk depends on nothing but the query,
+    so two renders agree bit for bit, and the strips of two ranks put together are the image of one."""
+    s, _ = scene_and_oracle("final_frame0042", 320, 180, tmp_path)
+    tlas_ctx.upload(s)
+    tlas_ctx.render_pass(0, 3)
+    whole = [a.copy() for a in tlas_ctx.read_accumulators()]
+    tlas_ctx.clear()
+    tlas_ctx.render_pass(0, 3)
+    for a, b in zip(whole, tlas_ctx.read_accumulators()):
+        assert np.array_equal(a, b, equal_nan=True)
+    tlas_ctx.clear()
+    for rank in (0, 1):
+        tlas_ctx.set_partition(rank, 2, 8)
+        tlas_ctx.render_pass(0, 3)
+    tlas_ctx.set_partition(0, 1, 16)
+    for a, b in zip(whole, tlas_ctx.read_accumulators()):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_switching_back_restores_parity(tmp_path):
     """The switch takes effect at upload and only there: the same context renders bit-exact images again once it is
     off."""
