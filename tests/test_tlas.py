@@ -176,6 +176,30 @@ def test_walk_is_deterministic_and_partitions_like_the_scan(tlas_ctx, tmp_path):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_deep_mesh_under_the_walk(tlas_ctx, tmp_path):
+    """A mesh whose BVH is far deeper than the part of a query's stack that lives in LDS (126 k triangles, depth 22;
+    7 entries in LDS): the walk over the nodes, the marker under the mesh walk and the mesh's own entries share one
+    stack, most of which is in device memory here.  Against the oracle that culls by entry."""
+    src = crt.Scene.load_file(scene_path("proj5_box"))
+    syn = src.make_instanced(0, 20, seed=1, width=192, height=108)
+    flat = str(tmp_path / "instanced20.crtscene")
+    syn.save_file(flat)
+    o = orc.OracleScene(flat)
+    assert o.bvh(0)["depth"] > 17
+    tlas_ctx.upload(syn)
+    tlas_ctx.render_pass(0, 3)
+    tlas_ctx.convert(1.0, syn.srgb)
+    got = tlas_ctx.read_image()
+    orc.set_node_cull(True)
+    try:
+        want = orc.convert(o.render(0, 3)[0], o.srgb, 1.0)
+    finally:
+        orc.set_node_cull(False)
+    assert psnr(got, want) >= 40.0
+    assert (got == want).all(axis=-1).mean() >= 0.995
+    tlas_ctx.stats()      # raises if the kernel reported a protocol error
+
+
 def test_switching_back_restores_parity(tmp_path):
     """The switch takes effect at upload and only there: the same context renders bit-exact images again once it is
     off."""
