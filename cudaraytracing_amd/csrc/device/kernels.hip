@@ -52,6 +52,14 @@
 // Arithmetic keeps the reference's operation order (see crt_vec.h); the file is
 // compiled with -ffp-contract=off and uses the pinned transcendentals of
 // crt_detmath.h, so results equal the CPU oracle bit for bit.
+//
+// One variant does not: kTlas, chosen by the caller for scenes of very many nodes
+// (crt_set_tlas).  Its queries walk a BVH over the scene's object nodes - BOX
+// steps over box pairs as inside a mesh, a NODE step in and out of every object
+// the walk reaches - instead of scanning the node list from end to end
+// (renderer/trace.cu:51, 166), and cull boxes by the distance at which the ray
+// enters them.  Objects are met in another order than the reference meets them,
+// so ties and last bits differ.
 #include <hip/hip_runtime.h>
 
 #include <float.h>
