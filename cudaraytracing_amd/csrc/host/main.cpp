@@ -16,7 +16,9 @@
 
 static void usage() {
     printf("usage: crt_render <scene.xml|scene.crtscene> [-o out.png] [--spp N] [--passes N] [--width W --height H]\n"
-           "                  [--assets DIR] [--device N]\n"
+           "                  [--assets DIR] [--device N] [--tlas]\n"
+           "           --tlas: walk a BVH over the scene's object nodes instead of scanning the node list; for scenes of hundreds\n"
+           "           of nodes and more, images are then no longer the reference's bit for bit\n"
            "       crt_render --sequence <dir> [--out-dir DIR] [--devices N] [--workers-per-device K] [same options]\n"
            "           every *.xml (or *.crtscene) of <dir>, one frame per worker: frames are handed out from a queue to\n"
            "           N x K workers, worker w renders on device w %% N (K > 1 overlaps one frame's scene load and BVH\n"
@@ -71,6 +73,7 @@ int main(int argc, char** argv) {
         else if (a == "--height") st.height = (uint32_t)atoi(val());
         else if (a == "--assets") st.asset_root = val();
         else if (a == "--device") st.device = atoi(val());
+        else if (a == "--tlas") st.tlas = true;
         else if (a == "--sequence") seq_dir = val();
         else if (a == "--out-dir") out_dir = val();
         else if (a == "--devices") devices = std::max(1, atoi(val()));

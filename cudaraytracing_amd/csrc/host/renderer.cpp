@@ -51,7 +51,7 @@ bool Renderer::LoadScene(const char* filename) {
         printf("ERROR: %s\n", lastError.c_str());
         return false;
     }
-    if (crt_upload_scene(ctx, &desc) != CRT_OK) {
+    if (crt_set_tlas(ctx, settings.tlas ? 1 : 0) != CRT_OK || crt_upload_scene(ctx, &desc) != CRT_OK) {
         lastError = crt_last_error(ctx);
         printf("ERROR: %s\n", lastError.c_str());
         return false;

@@ -35,6 +35,7 @@ struct RenderSettings {
     uint32_t height = 0;
     int device = 0;
     std::string asset_root;   // where relative mesh / texture paths resolve; empty = current directory
+    bool tlas = false;        // walk a BVH over the scene's object nodes instead of scanning the node list (crt_set_tlas: faster on scenes of hundreds of nodes, images no longer the reference's bit for bit)
 };
 
 class Renderer {

@@ -51,6 +51,19 @@ def test_single_frame_png_equals_the_oracle(tmp_path):
     assert np.array_equal(read_png(out), oracle_image("final_frame0042", 160, 90, 2, 2))
 
 
+def test_tlas_switch_of_the_command_line(tmp_path):
+    """--tlas selects the walk over a BVH of the scene nodes (not bit-exact: PSNR against the oracle's image as for the
+    mode's own tests; a sphere scene has nothing for the two to disagree on)."""
+    out = tmp_path / "box.png"
+    run(scene_path("proj5_box"), "-o", out, "--spp", 4, "--width", 320, "--height", 180, "--tlas")
+    got, want = read_png(out), oracle_image("proj5_box", 320, 180, 4, 1)
+    mse = np.mean((got.astype(np.float64) - want.astype(np.float64)) ** 2)
+    assert mse > 0 and 10 * np.log10(255.0 ** 2 / mse) >= 30.0
+    out = tmp_path / "ball.png"
+    run(scene_path("proj1_ball"), "-o", out, "--spp", 2, "--width", 160, "--height", 90, "--tlas")
+    assert np.array_equal(read_png(out), oracle_image("proj1_ball", 160, 90, 2, 1))
+
+
 @pytest.mark.parametrize("workers", [1, 3])
 def test_sequence_renders_every_frame_of_a_directory(tmp_path, workers):
     frames = {"a_first": "proj13_box", "b_second": "proj1_snowman", "c_third": "proj5_box", "d_fourth": "proj13_box"}
