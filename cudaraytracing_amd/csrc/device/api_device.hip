@@ -35,6 +35,8 @@ struct crt_ctx {
     bool order_valid = false;
     bool deep = false;                         // BVH deeper than the LDS stack: kDeep kernels
     bool regroup = false;                      // the kernels whose waves regroup queries by operation (kRegroup)
+    uint32_t mesh_nodes = 0;                   // scene nodes that hold a mesh
+    int64_t tail_window_knob = -1;             // CRT_TAIL_WINDOW, or -1: the usual window for the partition (set_partition)
     bool want_tlas = false;                    // crt_set_tlas: asked for by the caller, takes effect at the next upload
     bool tlas = false;                         // the uploaded scene is walked through a BVH over its object nodes (kTlas)
     uint32_t stack_overflow = 0;               // stack entries per thread kept in the side buffer
@@ -385,6 +387,11 @@ void set_partition(crt_ctx* ctx, uint32_t part, uint32_t parts, uint32_t strip_r
     P.tile_order = nullptr;
     P.tile_cost = nullptr;
     P.self_reset = 0;
+    {
+        const uint64_t in_flight = (uint64_t)ctx->num_cus * ctx->S.slots, fifth = P.total_items / 5;
+        const uint32_t usual = ctx->regroup && ctx->mesh_nodes > 0 ? (uint32_t)(in_flight < fifth ? in_flight : fifth) : 0u;
+        P.tail_window = ctx->tail_window_knob >= 0 ? (uint32_t)ctx->tail_window_knob : usual;
+    }
     ctx->order_valid = false;                  // costs of another partition say nothing about this one
 }
 
@@ -636,6 +643,7 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
         const uint32_t usual = CRT_BLOCK / 64 * 12 / 16;
         uint32_t mesh_nodes = 0;
         for (uint32_t i = 0; i < N; i++) mesh_nodes += d->nodes[i].object_kind == CRT_OBJ_MESH ? 1u : 0u;
+        ctx->mesh_nodes = mesh_nodes;
         uint32_t split = usual;
         if (stack_total * usual * 64 * 8 > kLdsLimit) split = usual + 1;
         else if (mesh_nodes == 0) split = usual - 3;
@@ -778,6 +786,14 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     S.serve_priority = crt::knob_value(getenv("CRT_SERVE_PRIORITY"), 1, 0, 1);
     S.pair_live = crt::knob_value(getenv("CRT_PAIR_LIVE"), ctx->deep ? (1u << 20) : S.trav_waves * 80, 0, 1u << 20);
     S.pair_below = crt::knob_value(getenv("CRT_PAIR_BELOW"), 0, 0, 1u << 20);
+    // End of the pixel queue (regrouping kernels): within the last "as many pixels as the GPU holds at a time" (but no more
+    // than a fifth of the partition) a block keeps only contexts - 128 of its slots supplied, so that less is in
+    // flight when the queue runs dry and the blocks finish closer together.  Measured on the benchmark frame: 139.9 ->
+    // 137.9 ms, 2 to 3 % on the other scenes with meshes; a window of a quarter of the frame or a floor below 450 slots
+    // lose it again.  Scenes without a mesh (queries of a few steps: the shading turns are what a block waits for, and they
+    // want every slot) were 4 to 5 % slower with it and keep all slots supplied to the end.
+    ctx->tail_window_knob = getenv("CRT_TAIL_WINDOW") ? (int64_t)crt::knob_value(getenv("CRT_TAIL_WINDOW"), 0, 0, 0x7fffffff) : -1;
+    S.tail_live = crt::knob_value(getenv("CRT_TAIL_LIVE"), ctx->regroup && S.contexts > 256 ? S.contexts - 128 : S.slots, 64, 1u << 20);
     S.fault_inject = crt::knob_value(getenv("CRT_FAULT_INJECT"), 0, 0, 1);      // tests only: the kernel loses one query, so that its watchdog has something to find
     S.watchdog_ticks = 100000000ull * crt::knob_value(getenv("CRT_WATCHDOG_SECONDS"), 30, 1, 3600);
     ctx->interleave = crt::knob_value(getenv("CRT_TILE_INTERLEAVE"), 0, 0, 1) != 0;

@@ -135,6 +135,7 @@ struct DevScene {
     uint32_t direct_start;           // shading lanes put a new query straight into a free query context when one is within reach
     uint32_t swing_waves, swing_fill;   // this many of the traversal waves take a shading turn when at least swing_fill slots wait for one
     uint32_t burst_max;              // turns of one operation between two votes, at most
+    uint32_t tail_live;              // once the pixel queue is nearly empty (DevPartition::tail_window), a block keeps only this many of its slots supplied
     uint32_t pair_below;             // a light sample's shadow query and the next segment's query start together while fewer than this many queries wait for traversal lanes
     uint32_t fault_inject;           // tests: block 0 drops one ray query on the floor (the watchdog then ends the launch with an error)
     unsigned long long watchdog_ticks;   // 100 MHz ticks a wave may find nothing to do before it reports a protocol error
@@ -181,6 +182,7 @@ struct DevPartition {
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     uint32_t self_reset;         // the launch leaves the pixel queue's counter at zero for the next one (no memset between launches)
+    uint32_t tail_window;        // queue items from the end of the queue within which blocks stop refilling all of their slots (0: never)
 };
 
 struct DevStats {

@@ -1286,6 +1286,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
     const float OVERPI = (float)(1.0f / 3.14159265358979323846);
     const float inv_samples = 1.0f / (float)samples;
     bool queue_empty = false;
+    uint32_t queue_seen = 0;      // where the pixel queue stood when this wave last took pixels from it
     bool fault_done = false, lose_first = false;
     bool direct_first = false, direct_second = false;      // the turn's queries went straight into query contexts (write_query)
     // The traversal lanes of the whole block wait on what these few waves produce: they go first whenever they
@@ -1337,12 +1338,27 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void trace_kernel(De
             const unsigned long long mask = __ballot(need);
             if (mask != 0) {
                 if (kCount) { tally.turns[5]++; tally.lanes[5] += need; }
+                // Towards the end of the queue a block stops refilling all of its slots: when the last pixels are handed
+                // out, every block still has to finish what its slots hold (whole pixels, each a serial chain of
+                // samples), and the less that is, the closer together the blocks finish.  Slots beyond S.tail_live
+                // retire instead of taking a pixel once fewer than S.tail_window pixels are left; the pixels they leave
+                // go to whichever block asks next.  (Which slot renders a pixel changes nothing about the pixel.)
+                unsigned long long fetchers = mask;
+                if (!queue_empty && P.total_items - queue_seen < P.tail_window) {
+                    const uint32_t live_now = lds_ld(&ctl.live);
+                    const uint32_t spare = live_now > S.tail_live ? live_now - S.tail_live : 0u;
+                    if (need && lane_rank(mask) < spare) result = R_RETIRE;
+                    fetchers = __ballot(need && result == R_NONE);
+                }
                 if (queue_empty) { if (need) result = R_RETIRE; }
-                else {
+                else if (fetchers != 0) {
+                    const unsigned long long mask = fetchers;
+                    const bool need = (fetchers >> lane) & 1ull;
                     uint32_t base = 0;
                     const uint32_t cnt = (uint32_t)__popcll(mask);
                     if (need && lane_rank(mask) == 0) base = atomicAdd(queue, cnt);
                     base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+                    queue_seen = base + cnt < P.total_items ? base + cnt : P.total_items;
                     if (base + cnt >= P.total_items) {      // uniform: the queue has run dry
                         queue_empty = true;
                         if (kCount && lane_rank(__ballot(true)) == 0 && wave_clock[wave * 2 + 1] == 0) wave_clock[wave * 2 + 1] = __builtin_amdgcn_s_memtime();

@@ -15,7 +15,7 @@ if os.environ.get("SWEEP_COPIES"):      # the synthetic instanced scene: SWEEP_S
 else:
     s.set_resolution(w, h)
 KNOBS = ("SCHED_BOX_MIN", "SCHED_SPECIAL_MIN", "SCHED_EXCHANGE_MIN", "TRAV_WAVES", "SLOTS", "SERVE_BATCH_MIN", "SERVE_LOW_WATER", "SERVE_PATIENCE", "SERVE_PRIORITY", "TILE_INTERLEAVE", "NO_BALANCE", "PAIR_BELOW", "PAIR_LIVE", "STACK_ENTRIES", "FIRST_STEP",
-         "REGROUP", "CONTEXTS", "KEEP_BOX", "KEEP_LEAF", "KEEP_NODE", "KEEP_EXCHANGE", "EXCHANGE_FIRST", "BURST_MAX", "DIRECT_START", "FIRST_STEP_IDLE", "SWING_WAVES", "SWING_FILL")
+         "REGROUP", "CONTEXTS", "KEEP_BOX", "KEEP_LEAF", "KEEP_NODE", "KEEP_EXCHANGE", "EXCHANGE_FIRST", "BURST_MAX", "DIRECT_START", "FIRST_STEP_IDLE", "SWING_WAVES", "SWING_FILL", "TAIL_WINDOW", "TAIL_LIVE")
 for spec in sys.argv[2:] or [""]:
     for k in KNOBS:
         os.environ.pop("CRT_" + k, None)
