@@ -200,6 +200,25 @@ def test_deep_mesh_under_the_walk(tlas_ctx, tmp_path):
     tlas_ctx.stats()      # raises if the kernel reported a protocol error
 
 
+def test_scene_without_objects(gpu_ctx, tlas_ctx, tmp_path):
+    """Nothing to build a tree over: every query ends at once, and both modes render the same (environment only)."""
+    (tmp_path / "empty.xml").write_text(
+        '<xml><scene><background r="0.2" g="0.4" b="0.6"/><environment r="0.2" g="0.4" b="0.6"/>'
+        '<light type="point" name="l"><intensity value="10"/><position x="0" y="0" z="5"/><size value="1"/></light></scene>'
+        '<camera><position x="0" y="-5" z="1"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="40"/>'
+        '<width value="96"/><height value="64"/></camera></xml>')
+    s = crt.Scene.load_xml(str(tmp_path / "empty.xml"), str(tmp_path))
+    images = []
+    for ctx in (gpu_ctx, tlas_ctx):
+        ctx.upload(s)
+        ctx.clear()
+        ctx.render_pass(0, 2)
+        ctx.stats()
+        images.append([a.copy() for a in ctx.read_accumulators()])
+    for a, b in zip(*images):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_switching_back_restores_parity(tmp_path):
     """The switch takes effect at upload and only there: the same context renders bit-exact images again once it is
     off."""
