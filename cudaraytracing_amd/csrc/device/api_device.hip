@@ -574,8 +574,27 @@ int crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* d) {
     // ---- opt-in: a BVH over the object nodes in place of the reference's node scans (trace.cu:51, 166)
     ctx->tlas = crt::knob_value(getenv("CRT_TLAS"), ctx->want_tlas ? 1 : 0, 0, 1) != 0;
     uint32_t tlas_root = make_leaf_ref(0, 0), tlas_depth = 0;
+    const uint64_t tlas_first = pairs.size();      // (records from here on belong to the BVH over the nodes)
     if (ctx->tlas) tlas_build(d, pairs, tlas_root, tlas_depth);
     if (pairs.size() >= 0x80000000ull) return fail(ctx, CRT_E_LIMIT, "too many BVH nodes");
+    // Every reference the kernels will follow, checked against the arrays before anything is uploaded: a kernel that
+    // walks out of an array faults the GPU, so a slip of the builders above must end here, as an error.
+    {
+        const uint64_t n_pairs = pairs.size(), n_tris = tris.size();
+        auto ref_ok = [&](uint32_t ref, bool top_level) -> bool {
+            if (!ref_is_leaf(ref)) return ref >= N && ref < n_pairs;
+            const uint32_t count = leaf_count(ref);
+            if (count == kTlasEnter) return top_level && leaf_start(ref) < N;
+            if (count == kTlasLeave) return false;      // (only ever on a stack)
+            return count <= kLeafMost && (uint64_t)leaf_start(ref) + count <= n_tris;
+        };
+        bool ok = true;
+        for (uint32_t i = 0; i < N && ok; i++) ok = node_ref_after(pairs[i].ref_a) <= N && node_ref_after(pairs[i].ref_b) <= N;
+        for (uint64_t i = N; i < n_pairs && ok; i++) ok = ref_ok(pairs[i].ref_a, i >= tlas_first) && ref_ok(pairs[i].ref_b, i >= tlas_first);
+        for (uint32_t m = 0; m < d->mesh_count && ok; m++) ok = ref_ok(mesh_root[m], false);
+        ok = ok && ref_ok(tlas_root, true);
+        if (!ok) return fail(ctx, CRT_E_INVALID, "internal error: a BVH record refers outside the scene's arrays");
+    }
 
     std::vector<NodeXf> xf(N);
     for (uint32_t i = 0; i < N; i++) {
